@@ -1,0 +1,59 @@
+// Shared helpers for the gfx950 kernels of the GAIA-seg supernet hot path.
+// (MI355X only: 64-lane waves, 256 CUs in 8 XCDs; no other target is supported.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gaiaseg_hip.h"
+
+namespace gs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;      // CDNA wavefront
+constexpr int kNumCU = 256;    // MI355X
+constexpr int kNumXCD = 8;
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Returns 0 or the positive hipError_t of the most recent launch on this thread.
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? GS_OK : static_cast<int>(e);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid size for a memory-bound grid-stride kernel: enough blocks to fill the chip
+// (256 CUs x 8 blocks), never more than the work needs.
+inline int stream_grid(int64_t work_items, int block) {
+  int64_t g = ceil_div(work_items, block);
+  const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return static_cast<int>(g);
+}
+
+// Bijective XCD remap (blocks b and b+8 share an XCD under round-robin dispatch): gives every
+// XCD a contiguous chunk of the tile sequence so neighbouring tiles hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg / kNumXCD, r = nwg % kNumXCD;
+  const int xcd = bid % kNumXCD, idx = bid / kNumXCD;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+// Wave-level sum (64 lanes).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+}  // namespace gs

@@ -1,0 +1,726 @@
+// Dynamic (slimmable) convolution for gfx950 as implicit GEMM on the fp32 MFMA
+// (v_mfma_f32_16x16x4_f32: exact fp32, bit-for-bit an fmaf chain — the reference path is fp32
+// throughout, gaiaseg/models/decode_heads/dynamic_fcn_head.py:81).
+//
+// Replaces F.conv2d(x, weight[:Co,:Ci], ...) of gaiavision DynConv2d and its autograd backward at
+// the call sites of gaiaseg/models/utils/dynamic_res_layer.py:84-125,
+// gaiaseg/models/backbones/dynamic_resnet.py:255-302 and the decode heads
+// (dynamic_fcn_head.py:76-126, dynamic_psp_head.py:53-59,123,140-147, dynamic_uper_head.py:40-79).
+//
+// Layout: activations NHWC (pixel stride ld), weights physical [KH][KW][Ci_max][Co_ld]; the active
+// leading slice [:Ci,:Co] is read in place (runtime Ci/Co — one binary for all 85k subnets).
+//
+// Three GEMM views share one tile engine (256 threads = 4 waves stacked along M, BK = 16):
+//   forward : Y[m, co]  = sum_{tap,ci} Xg[m,(tap,ci)] * W[tap][ci][co]      m = output pixel
+//   dgrad   : dX[m, ci] = sum_{tap,co} dYg[m,(tap,co)] * W[tap][ci][co]     m = input pixel
+//   wgrad   : dW[(tap,ci), co] = sum_m Xg[m,(tap,ci)] * dY[m, co]           K = pixels (split-K)
+// A and B tiles are staged global -> registers -> LDS (issue-early / write-late double buffer, one
+// barrier per K step); LDS images are k-major with a per-4-row skew so that both the transposed
+// stores and the MFMA fragment reads (lane l reads [k = l>>4][i = l&15]) are bank-conflict free.
+#include <algorithm>
+#include "common.h"
+
+namespace gs {
+
+constexpr int BK = 16;
+constexpr int NT = 256;
+
+struct IgemmArgs {
+  const float* src;    // gathered operand (x for forward / wgrad, dy for dgrad)
+  const float* dense;  // dense operand (w for forward / dgrad, dy for wgrad)
+  float* out;
+  float* slab;         // split-K partials [splits][M][Nn] (NULL when splits == 1)
+  const float* bias;
+  const float* addend;
+  long s_n, s_h, s_w, s_c;  // element strides of src
+  int Hs, Ws, Cs;           // src spatial dims, channels gathered per tap
+  int Hp, Wp;               // pixel-row space (forward/wgrad: output pixels, dgrad: input pixels)
+  int npix;                 // Nb * Hp * Wp
+  int KW, taps;
+  int mul_h, mul_w, base_h, base_w, step_h, step_w, div_h, div_w;
+  long d_tap;               // dense tap stride (weights)
+  int d_row;                // forward: stride of ci rows; dgrad: stride of ci rows (n index);
+                            // wgrad: pixel stride of dy
+  int n_lim;                // forward/wgrad: number of dense columns that may be read (mult. of 4)
+  int M, Nn, Ktot;          // GEMM sizes; wgrad: M = taps*Cs, Ktot = npix
+  int ld_out, ld_add;
+  long o_tap;               // wgrad: dw tap stride
+  int o_row;                // wgrad: dw ci-row stride
+  int nk_total, nk_per_split;
+  int accumulate;
+  int tiles_m, tiles_n;
+};
+
+// k-major LDS image with skew: element (k, i) at k*P + 8*(k>>2) + i, P % 32 == 16.
+//  * MFMA fragment read (ds_read_b32, lanes 0-31 hold k = 4ks + {0,1}, i = 0..15): rows k and k+1
+//    start 16 banks apart -> 32 distinct banks.
+//  * transposed store (lane -> (i = t>>2, kq = t&3), element j): rows kq*4+j start 8*kq (+16*(j&1))
+//    banks apart -> the 8 consecutive i of 4 kq cover 32 distinct banks.
+template <int BM, int BN>
+struct Tile {
+  static constexpr int PA = BM + 16;
+  static constexpr int PB = ((BN + 31) / 32) * 32 + 16;
+  static constexpr int A_SZ = BK * PA + 32;
+  static constexpr int B_SZ = BK * PB + 32;
+  static constexpr int STAGE = A_SZ + B_SZ;
+  static constexpr int CCH = BN < 64 ? BN : 64;  // epilogue column chunk
+  static constexpr int PC = CCH + 4;
+  static constexpr int C_SZ = BM * PC;
+  static constexpr int LDSF = (2 * STAGE > C_SZ) ? 2 * STAGE : C_SZ;
+  static constexpr int WM = BM / 4;   // rows per wave
+  static constexpr int TM = WM / 16;  // 16x16 tiles per wave along M
+  static constexpr int TN = BN / 16;
+  static constexpr int BV = (BK * BN / 4 + NT - 1) / NT;  // dense float4 per thread
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const float* __restrict__ Bs,
+                                           f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN],
+                                           int wave, int lane) {
+  using T = Tile<BM, BN>;
+  const int kk = lane >> 4, li = lane & 15;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int ko = ks * 4 + kk;
+    float a[T::TM], b[T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) a[i] = As[ko * T::PA + 8 * ks + wave * T::WM + i * 16 + li];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) b[j] = Bs[ko * T::PB + 8 * ks + j * 16 + li];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// Accumulators -> LDS (column chunk `ch`) in [row][col] order.  C/D map of the 16x16 MFMA:
+// col = lane & 15, row = (lane >> 4) * 4 + reg.
+template <int BM, int BN>
+__device__ __forceinline__ void acc_to_lds(float* __restrict__ Cs,
+                                           const f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN],
+                                           int ch, int wave, int lane) {
+  using T = Tile<BM, BN>;
+  constexpr int TPC = T::CCH / 16;  // 16-col tiles per chunk
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < TPC; ++jj) {
+      const int j = ch * TPC + jj;
+      if (j < T::TN) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Cs[(wave * T::WM + i * 16 + (lane >> 4) * 4 + r) * T::PC + jj * 16 + (lane & 15)] =
+              acc[i][j][r];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / dgrad: GEMM rows are pixels, the gathered operand is A.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, bool BTRANS, bool DIVS, bool SCALAR>
+__global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
+  using T = Tile<BM, BN>;
+  __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
+  constexpr int AS = BM / 64;  // A float4 slots per thread
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kt0 = blockIdx.y * p.nk_per_split;
+  const int kt1 = min(kt0 + p.nk_per_split, p.nk_total);
+
+  // per-thread row geometry (constant over the K loop)
+  const int kq = t & 3;
+  int hb[AS], wb[AS];
+  long nb[AS];
+  bool rv[AS];
+  const int hw = p.Hp * p.Wp;
+#pragma unroll
+  for (int s = 0; s < AS; ++s) {
+    const int m = m0 + (t >> 2) + 64 * s;
+    rv[s] = m < p.M;
+    const int mm = rv[s] ? m : 0;
+    const int n = mm / hw;
+    const int rem = mm - n * hw;
+    const int hp = rem / p.Wp;
+    const int wp = rem - hp * p.Wp;
+    hb[s] = hp * p.mul_h + p.base_h;
+    wb[s] = wp * p.mul_w + p.base_w;
+    nb[s] = (long)n * p.s_n;
+  }
+
+  // block-uniform (tap, channel) of the first k of the current K step
+  int tap_u = (kt0 * BK) / p.Cs;
+  int c_u = kt0 * BK - tap_u * p.Cs;
+
+  f32x4 ra[AS];
+  f32x4 rb[T::BV];
+  f32x4 acc[T::TM][T::TN];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto gather = [&](int s, int tap, int c) -> const float* {
+    // returns the address of src element for row slot s / (tap, c), or nullptr when padded
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int hn = hb[s] + kh * p.step_h, wn = wb[s] + kw * p.step_w;
+    int hi = hn, wi = wn;
+    bool ok = rv[s] && tap < p.taps;
+    if constexpr (DIVS) {
+      ok = ok && hn >= 0 && wn >= 0;
+      hi = hn / p.div_h;
+      wi = wn / p.div_w;
+      ok = ok && hi * p.div_h == hn && wi * p.div_w == wn;
+    }
+    ok = ok && (unsigned)hi < (unsigned)p.Hs && (unsigned)wi < (unsigned)p.Ws;
+    return ok ? p.src + nb[s] + (long)hi * p.s_h + (long)wi * p.s_w + (long)c * p.s_c : nullptr;
+  };
+
+  auto load_tiles = [&](int kt) {
+    // ---- A (gathered) ----
+    if constexpr (!SCALAR) {
+      int c = c_u + kq * 4, tap = tap_u;
+      while (c >= p.Cs) { c -= p.Cs; ++tap; }
+#pragma unroll
+      for (int s = 0; s < AS; ++s) {
+        const float* q = gather(s, tap, c);
+        ra[s] = q ? *reinterpret_cast<const f32x4*>(q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < AS; ++s) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = kt * BK + kq * 4 + e;
+          const int tap = k / p.Cs, c = k - tap * p.Cs;
+          const float* q = gather(s, tap, c);
+          ra[s][e] = q ? *q : 0.f;
+        }
+      }
+    }
+    // ---- B (dense) ----
+#pragma unroll
+    for (int r = 0; r < T::BV; ++r) {
+      const int idx = t + NT * r;
+      rb[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < BK * BN / 4) {
+        if constexpr (!BTRANS) {
+          const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
+          int c, tap;
+          if constexpr (SCALAR) {
+            const int k = kt * BK + kr;
+            tap = k / p.Cs;
+            c = k - tap * p.Cs;
+          } else {
+            c = c_u + kr;
+            tap = tap_u;
+            while (c >= p.Cs) { c -= p.Cs; ++tap; }
+          }
+          const int col = n0 + nq * 4;
+          if (tap < p.taps && col < p.n_lim)
+            rb[r] = *reinterpret_cast<const f32x4*>(p.dense + (long)tap * p.d_tap +
+                                                    (long)c * p.d_row + col);
+        } else {
+          const int nrow = idx >> 2, kq2 = idx & 3;
+          int c = c_u + kq2 * 4, tap = tap_u;
+          while (c >= p.Cs) { c -= p.Cs; ++tap; }
+          const int ng = n0 + nrow;
+          if (tap < p.taps && ng < p.Nn)
+            rb[r] = *reinterpret_cast<const f32x4*>(p.dense + (long)tap * p.d_tap +
+                                                    (long)ng * p.d_row + c);
+        }
+      }
+    }
+    // advance the uniform (tap, c) to the next K step
+    c_u += BK;
+    while (c_u >= p.Cs) { c_u -= p.Cs; ++tap_u; }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* As = lds + buf * T::STAGE;
+    float* Bs = As + T::A_SZ;
+#pragma unroll
+    for (int s = 0; s < AS; ++s) {
+      const int row = (t >> 2) + 64 * s;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * T::PA + 8 * kq + row] = ra[s][j];
+    }
+#pragma unroll
+    for (int r = 0; r < T::BV; ++r) {
+      const int idx = t + NT * r;
+      if (idx < BK * BN / 4) {
+        if constexpr (!BTRANS) {
+          const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
+          *reinterpret_cast<f32x4*>(&Bs[kr * T::PB + 8 * (kr >> 2) + nq * 4]) = rb[r];
+        } else {
+          const int nrow = idx >> 2, kq2 = idx & 3;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Bs[(kq2 * 4 + j) * T::PB + 8 * kq2 + nrow] = rb[r][j];
+        }
+      }
+    }
+  };
+
+  if (kt0 < kt1) {
+    load_tiles(kt0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+      if (more) load_tiles(kt + 1);  // global loads in flight under the MFMAs
+      mfma_stage<BM, BN>(lds + buf * T::STAGE, lds + buf * T::STAGE + T::A_SZ, acc, wave, lane);
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: accumulators -> LDS -> coalesced float4 rows ----
+  float* Cs = lds;
+  constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch > 0) __syncthreads();
+    acc_to_lds<BM, BN>(Cs, acc, ch, wave, lane);
+    __syncthreads();
+    constexpr int QPR = T::CCH / 4;  // float4 per row of a full chunk
+    for (int idx = t; idx < BM * QPR; idx += NT) {
+      const int row = idx / QPR, q = idx - row * QPR;
+      const int m = m0 + row;
+      const int col = n0 + ch * T::CCH + q * 4;
+      if (ch * T::CCH + q * 4 < BN && m < p.M && col < p.Nn) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * T::PC + q * 4]);
+        if (p.slab) {
+          *reinterpret_cast<f32x4*>(p.slab + ((long)blockIdx.y * p.M + m) * p.Nn + col) = v;
+        } else {
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+          if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (long)m * p.ld_add + col);
+          float* o = p.out + (long)m * p.ld_out + col;
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+          *reinterpret_cast<f32x4*>(o) = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: GEMM rows are (tap, ci), K runs over pixels; both operands are k-major in memory.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, bool SCALAR>
+__global__ __launch_bounds__(NT) void igemm_wgrad_kernel(const IgemmArgs p) {
+  using T = Tile<BM, BN>;
+  __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
+  constexpr int QA = BM / 4;        // float4 per k-row of A
+  constexpr int AS = BK * QA / NT;  // A float4 slots per thread (1 or 2)
+  constexpr int KSTR = NT / QA;     // k rows covered per slot
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int i0 = tm * BM, n0 = tn * BN;
+  const int kt0 = blockIdx.y * p.nk_per_split;
+  const int kt1 = min(kt0 + p.nk_per_split, p.nk_total);
+
+  // fixed (tap, c) of this thread's 4 GEMM rows
+  const int iq = t % QA, krA = t / QA;
+  int offh[SCALAR ? 4 : 1], offw[SCALAR ? 4 : 1];
+  long offc[SCALAR ? 4 : 1];
+  bool iv[SCALAR ? 4 : 1];
+#pragma unroll
+  for (int e = 0; e < (SCALAR ? 4 : 1); ++e) {
+    const int i = i0 + iq * 4 + e;
+    iv[e] = i < p.M;
+    const int ii = iv[e] ? i : 0;
+    const int tap = ii / p.Cs, c = ii - tap * p.Cs;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    offh[e] = p.base_h + kh * p.step_h;
+    offw[e] = p.base_w + kw * p.step_w;
+    offc[e] = (long)c * p.s_c;
+  }
+  const int hw = p.Hp * p.Wp;
+
+  f32x4 ra[AS];
+  f32x4 rb[T::BV];
+  f32x4 acc[T::TM][T::TN];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int s = 0; s < AS; ++s) {
+      const int m = kt * BK + krA + s * KSTR;
+      const bool mv = m < p.npix;
+      const int mm = mv ? m : 0;
+      const int n = mm / hw;
+      const int rem = mm - n * hw;
+      const int hp = rem / p.Wp;
+      const int wp = rem - hp * p.Wp;
+      const long nbase = (long)n * p.s_n;
+      const int hbase = hp * p.mul_h, wbase = wp * p.mul_w;
+      if constexpr (!SCALAR) {
+        const int hi = hbase + offh[0], wi = wbase + offw[0];
+        const bool ok = mv && iv[0] && (unsigned)hi < (unsigned)p.Hs && (unsigned)wi < (unsigned)p.Ws;
+        ra[s] = ok ? *reinterpret_cast<const f32x4*>(p.src + nbase + (long)hi * p.s_h +
+                                                     (long)wi * p.s_w + offc[0])
+                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int hi = hbase + offh[e], wi = wbase + offw[e];
+          const bool ok =
+              mv && iv[e] && (unsigned)hi < (unsigned)p.Hs && (unsigned)wi < (unsigned)p.Ws;
+          ra[s][e] = ok ? p.src[nbase + (long)hi * p.s_h + (long)wi * p.s_w + offc[e]] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < T::BV; ++r) {
+      const int idx = t + NT * r;
+      rb[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < BK * BN / 4) {
+        const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
+        const int m = kt * BK + kr;
+        const int col = n0 + nq * 4;
+        if (m < p.npix && col < p.n_lim)
+          rb[r] = *reinterpret_cast<const f32x4*>(p.dense + (long)m * p.d_row + col);
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* As = lds + buf * T::STAGE;
+    float* Bs = As + T::A_SZ;
+#pragma unroll
+    for (int s = 0; s < AS; ++s) {
+      const int kr = krA + s * KSTR;
+      *reinterpret_cast<f32x4*>(&As[kr * T::PA + 8 * (kr >> 2) + iq * 4]) = ra[s];
+    }
+#pragma unroll
+    for (int r = 0; r < T::BV; ++r) {
+      const int idx = t + NT * r;
+      if (idx < BK * BN / 4) {
+        const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
+        *reinterpret_cast<f32x4*>(&Bs[kr * T::PB + 8 * (kr >> 2) + nq * 4]) = rb[r];
+      }
+    }
+  };
+
+  if (kt0 < kt1) {
+    load_tiles(kt0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+      if (more) load_tiles(kt + 1);
+      mfma_stage<BM, BN>(lds + buf * T::STAGE, lds + buf * T::STAGE + T::A_SZ, acc, wave, lane);
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  float* Cs = lds;
+  constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch > 0) __syncthreads();
+    acc_to_lds<BM, BN>(Cs, acc, ch, wave, lane);
+    __syncthreads();
+    constexpr int QPR = T::CCH / 4;
+    for (int idx = t; idx < BM * QPR; idx += NT) {
+      const int row = idx / QPR, q = idx - row * QPR;
+      const int i = i0 + row;
+      const int col = n0 + ch * T::CCH + q * 4;
+      if (ch * T::CCH + q * 4 < BN && i < p.M && col < p.Nn) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * T::PC + q * 4]);
+        if (p.slab) {
+          *reinterpret_cast<f32x4*>(p.slab + ((long)blockIdx.y * p.M + i) * p.Nn + col) = v;
+        } else {
+          const int tap = i / p.Cs, c = i - tap * p.Cs;
+          *reinterpret_cast<f32x4*>(p.out + (long)tap * p.o_tap + (long)c * p.o_row + col) = v;
+        }
+      }
+    }
+  }
+}
+
+// Fixed-order sum of the split-K partial slabs + epilogue.  rows_are_taps selects the wgrad
+// output addressing.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, int splits,
+                                                            int rows_are_taps) {
+  const int qpr = p.Nn / 4;
+  const long total = (long)p.M * qpr;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / qpr);
+    const int col = (int)(idx - (long)row * qpr) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.slab + (long)row * p.Nn + col);
+    for (int z = 1; z < splits; ++z)
+      v += *reinterpret_cast<const f32x4*>(p.slab + ((long)z * p.M + row) * p.Nn + col);
+    if (rows_are_taps) {
+      const int tap = row / p.Cs, c = row - tap * p.Cs;
+      *reinterpret_cast<f32x4*>(p.out + (long)tap * p.o_tap + (long)c * p.o_row + col) = v;
+    } else {
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+      if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (long)row * p.ld_add + col);
+      float* o = p.out + (long)row * p.ld_out + col;
+      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: tile selection and launch
+// ------------------------------------------------------------------------------------------
+struct Plan {
+  int bm, bn, splits, nk_total, nk_per_split, tiles_m, tiles_n;
+};
+
+static const int kBN[6] = {128, 96, 80, 64, 48, 32};
+constexpr size_t kMaxSlabBytes = 96u << 20;
+
+static Plan make_plan(int M, int Nn, int Ktot, bool allow_split) {
+  Plan pl{};
+  // BN: least padded width, larger tile on ties
+  int best = 32, best_pad = 1 << 30;
+  for (int i = 0; i < 6; ++i) {
+    const int bn = kBN[i];
+    const int pad = (int)ceil_div(Nn, bn) * bn;
+    if (pad < best_pad) { best_pad = pad; best = bn; }
+  }
+  pl.bn = best;
+  pl.tiles_n = (int)ceil_div(Nn, pl.bn);
+  pl.nk_total = (int)ceil_div(Ktot, BK);
+  // BM: 128 when that still fills the chip, else 64
+  const long t128 = ceil_div(M, 128) * pl.tiles_n;
+  pl.bm = (t128 >= 2 * kNumCU) ? 128 : 64;
+  pl.tiles_m = (int)ceil_div(M, pl.bm);
+  const long tiles = (long)pl.tiles_m * pl.tiles_n;
+  int splits = 1;
+  if (allow_split && tiles < 2 * kNumCU && pl.nk_total >= 8) {
+    splits = (int)ceil_div(2 * kNumCU, tiles);
+    const int max_by_k = pl.nk_total / 4;  // at least 4 K steps per split
+    if (splits > max_by_k) splits = max_by_k;
+    if (splits > 64) splits = 64;
+    while (splits > 1 && (size_t)splits * M * Nn * sizeof(float) > kMaxSlabBytes) --splits;
+    if (splits < 1) splits = 1;
+  }
+  pl.nk_per_split = (int)ceil_div(pl.nk_total, splits);
+  pl.splits = (int)ceil_div(pl.nk_total, pl.nk_per_split);
+  return pl;
+}
+
+template <bool BTRANS, bool DIVS, bool SCALAR>
+static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
+  const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
+#define GS_ROWS(BM_, BN_)                                                                     \
+  if (pl.bm == BM_ && pl.bn == BN_) {                                                         \
+    hipLaunchKernelGGL((igemm_rows_kernel<BM_, BN_, BTRANS, DIVS, SCALAR>), grid, block, 0, st, a); \
+    return;                                                                                   \
+  }
+  GS_ROWS(128, 128) GS_ROWS(128, 96) GS_ROWS(128, 80) GS_ROWS(128, 64) GS_ROWS(128, 48) GS_ROWS(128, 32)
+  GS_ROWS(64, 128) GS_ROWS(64, 96) GS_ROWS(64, 80) GS_ROWS(64, 64) GS_ROWS(64, 48) GS_ROWS(64, 32)
+#undef GS_ROWS
+}
+
+template <bool SCALAR>
+static void launch_wgrad(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
+  const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
+#define GS_WG(BM_, BN_)                                                                \
+  if (pl.bm == BM_ && pl.bn == BN_) {                                                  \
+    hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, SCALAR>), grid, block, 0, st, a); \
+    return;                                                                            \
+  }
+  GS_WG(128, 128) GS_WG(128, 96) GS_WG(128, 80) GS_WG(128, 64) GS_WG(128, 48) GS_WG(128, 32)
+  GS_WG(64, 128) GS_WG(64, 96) GS_WG(64, 80) GS_WG(64, 64) GS_WG(64, 48) GS_WG(64, 32)
+#undef GS_WG
+}
+
+static int check_desc(const gs_conv_desc* d) {
+  if (!d) return GS_E_NULL;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Ci <= 0 || d->Co <= 0) return GS_E_BADARG;
+  if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0) return GS_E_BADARG;
+  if (d->Ci > d->Ci_max || d->Co > d->Co_ld) return GS_E_BADARG;
+  if ((d->Co & 3) || (d->Co_ld & 3) || (d->ldy & 3) || d->ldy < d->Co) return GS_E_ALIGN;
+  const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+  const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  if (ho != d->Ho || wo != d->Wo || ho <= 0 || wo <= 0) return GS_E_BADARG;
+  if ((long)d->N * d->H * d->W >= (1L << 31) || (long)d->N * ho * wo >= (1L << 31)) return GS_E_BADARG;
+  return GS_OK;
+}
+
+static bool x_is_vector(const gs_conv_desc* d) {
+  return d->x_sc == 1 && (d->Ci & 3) == 0 && (d->x_sw & 3) == 0 && (d->x_sh & 3) == 0 &&
+         (d->x_sn & 3) == 0;
+}
+
+static Plan plan_fwd(const gs_conv_desc* d) {
+  return make_plan(d->N * d->Ho * d->Wo, d->Co, d->KH * d->KW * d->Ci, true);
+}
+static Plan plan_dgrad(const gs_conv_desc* d) {
+  return make_plan(d->N * d->H * d->W, d->Ci, d->KH * d->KW * d->Co, true);
+}
+static Plan plan_wgrad(const gs_conv_desc* d) {
+  return make_plan(d->KH * d->KW * d->Ci, d->Co, d->N * d->Ho * d->Wo, true);
+}
+static size_t slab_bytes(const Plan& pl, long M, int Nn) {
+  return pl.splits > 1 ? (size_t)pl.splits * M * Nn * sizeof(float) : 0;
+}
+
+static void launch_reduce(const IgemmArgs& a, int splits, int rows_are_taps, hipStream_t st) {
+  const long total = (long)a.M * (a.Nn / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, a,
+                     splits, rows_are_taps);
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
+  if (check_desc(d) != GS_OK) return 0;
+  size_t b = 0;
+  {
+    const Plan pl = plan_fwd(d);
+    b = std::max(b, slab_bytes(pl, (long)d->N * d->Ho * d->Wo, d->Co));
+  }
+  if (d->x_sc == 1 && (d->Ci & 3) == 0) {
+    const Plan pl = plan_dgrad(d);
+    b = std::max(b, slab_bytes(pl, (long)d->N * d->H * d->W, d->Ci));
+  }
+  {
+    const Plan pl = plan_wgrad(d);
+    b = std::max(b, slab_bytes(pl, (long)d->KH * d->KW * d->Ci, d->Co));
+  }
+  return b;
+}
+
+extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const float* w,
+                                 const float* bias, const float* addend, float* y, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc != GS_OK) return rc;
+  if (!x || !w || !y) return GS_E_NULL;
+  if (!aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) || (addend && !aligned16(addend)))
+    return GS_E_ALIGN;
+  if (addend && ((d->ld_add & 3) || d->ld_add < d->Co)) return GS_E_ALIGN;
+  const bool vec = x_is_vector(d);
+  if (vec && !aligned16(x)) return GS_E_ALIGN;
+  const Plan pl = plan_fwd(d);
+  const long M = (long)d->N * d->Ho * d->Wo;
+  const size_t need = slab_bytes(pl, M, d->Co);
+  if (need > workspace_bytes || (need && !workspace)) return GS_E_WORKSPACE;
+
+  IgemmArgs a{};
+  a.src = x; a.dense = w; a.out = y; a.slab = need ? static_cast<float*>(workspace) : nullptr;
+  a.bias = bias; a.addend = addend;
+  a.s_n = d->x_sn; a.s_h = d->x_sh; a.s_w = d->x_sw; a.s_c = d->x_sc;
+  a.Hs = d->H; a.Ws = d->W; a.Cs = d->Ci;
+  a.Hp = d->Ho; a.Wp = d->Wo; a.npix = (int)M;
+  a.KW = d->KW; a.taps = d->KH * d->KW;
+  a.mul_h = a.mul_w = d->stride; a.base_h = a.base_w = -d->pad;
+  a.step_h = a.step_w = d->dil; a.div_h = a.div_w = 1;
+  a.d_tap = (long)d->Ci_max * d->Co_ld; a.d_row = d->Co_ld; a.n_lim = d->Co;
+  a.M = (int)M; a.Nn = d->Co; a.Ktot = a.taps * d->Ci;
+  a.ld_out = d->ldy; a.ld_add = d->ld_add;
+  a.nk_total = pl.nk_total; a.nk_per_split = pl.nk_per_split;
+  a.accumulate = 0; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
+  hipStream_t st = as_stream(stream);
+  if (vec) launch_rows<false, false, false>(pl, a, st);
+  else launch_rows<false, false, true>(pl, a, st);
+  rc = launch_status();
+  if (rc != GS_OK) return rc;
+  if (pl.splits > 1) {
+    launch_reduce(a, pl.splits, 0, st);
+    rc = launch_status();
+  }
+  return rc;
+}
+
+extern "C" int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
+                               int accumulate, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  int rc = check_desc(d);
+  if (rc != GS_OK) return rc;
+  if (!dy || !w || !dx) return GS_E_NULL;
+  if (d->x_sc != 1 || (d->Ci & 3) || (d->x_sw & 3)) return GS_E_ALIGN;
+  if (d->x_sh != (int64_t)d->W * d->x_sw || d->x_sn != (int64_t)d->H * d->x_sh) return GS_E_BADARG;
+  if (!aligned16(dy) || !aligned16(w) || !aligned16(dx)) return GS_E_ALIGN;
+  const Plan pl = plan_dgrad(d);
+  const long M = (long)d->N * d->H * d->W;
+  const size_t need = slab_bytes(pl, M, d->Ci);
+  if (need > workspace_bytes || (need && !workspace)) return GS_E_WORKSPACE;
+
+  IgemmArgs a{};
+  a.src = dy; a.dense = w; a.out = dx; a.slab = need ? static_cast<float*>(workspace) : nullptr;
+  a.s_c = 1; a.s_w = d->ldy; a.s_h = (long)d->Wo * d->ldy; a.s_n = (long)d->Ho * a.s_h;
+  a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;
+  a.Hp = d->H; a.Wp = d->W; a.npix = (int)M;
+  a.KW = d->KW; a.taps = d->KH * d->KW;
+  a.mul_h = a.mul_w = 1; a.base_h = a.base_w = d->pad;
+  a.step_h = a.step_w = -d->dil; a.div_h = a.div_w = d->stride;
+  a.d_tap = (long)d->Ci_max * d->Co_ld; a.d_row = d->Co_ld; a.n_lim = d->Ci;
+  a.M = (int)M; a.Nn = d->Ci; a.Ktot = a.taps * d->Co;
+  a.ld_out = (int)d->x_sw; a.ld_add = 0;
+  a.nk_total = pl.nk_total; a.nk_per_split = pl.nk_per_split;
+  a.accumulate = accumulate ? 1 : 0; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
+  hipStream_t st = as_stream(stream);
+  if (d->stride == 1) launch_rows<true, false, false>(pl, a, st);
+  else launch_rows<true, true, false>(pl, a, st);
+  rc = launch_status();
+  if (rc != GS_OK) return rc;
+  if (pl.splits > 1) {
+    launch_reduce(a, pl.splits, 0, st);
+    rc = launch_status();
+  }
+  return rc;
+}
+
+extern "C" int gs_conv2d_wgrad(const gs_conv_desc* d, const float* x, const float* dy, float* dw,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc != GS_OK) return rc;
+  if (!x || !dy || !dw) return GS_E_NULL;
+  if (!aligned16(dy) || !aligned16(dw)) return GS_E_ALIGN;
+  const bool vec = x_is_vector(d);
+  if (vec && !aligned16(x)) return GS_E_ALIGN;
+  const Plan pl = plan_wgrad(d);
+  const long M = (long)d->KH * d->KW * d->Ci;
+  const size_t need = slab_bytes(pl, M, d->Co);
+  if (need > workspace_bytes || (need && !workspace)) return GS_E_WORKSPACE;
+
+  IgemmArgs a{};
+  a.src = x; a.dense = dy; a.out = dw; a.slab = need ? static_cast<float*>(workspace) : nullptr;
+  a.s_n = d->x_sn; a.s_h = d->x_sh; a.s_w = d->x_sw; a.s_c = d->x_sc;
+  a.Hs = d->H; a.Ws = d->W; a.Cs = d->Ci;
+  a.Hp = d->Ho; a.Wp = d->Wo; a.npix = d->N * d->Ho * d->Wo;
+  a.KW = d->KW; a.taps = d->KH * d->KW;
+  a.mul_h = a.mul_w = d->stride; a.base_h = a.base_w = -d->pad;
+  a.step_h = a.step_w = d->dil; a.div_h = a.div_w = 1;
+  a.d_tap = 0; a.d_row = d->ldy; a.n_lim = d->Co;
+  a.M = (int)M; a.Nn = d->Co; a.Ktot = a.npix;
+  a.o_tap = (long)d->Ci_max * d->Co_ld; a.o_row = d->Co_ld;
+  a.nk_total = pl.nk_total; a.nk_per_split = pl.nk_per_split;
+  a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
+  hipStream_t st = as_stream(stream);
+  if (vec) launch_wgrad<false>(pl, a, st);
+  else launch_wgrad<true>(pl, a, st);
+  rc = launch_status();
+  if (rc != GS_OK) return rc;
+  if (pl.splits > 1) {
+    launch_reduce(a, pl.splits, 1, st);
+    rc = launch_status();
+  }
+  return rc;
+}

@@ -1,0 +1,295 @@
+// Pixel-wise cross entropy with on-the-fly bilinear upsampling of the logits — gfx950, HBM-bound.
+//
+// Replaces, in one pass over the labels, the chain of
+//   resize(seg_logit, size=label.shape[2:], 'bilinear')           (dynamic_fcn_head.py:141-145)
+//   F.cross_entropy(..., reduction='none', ignore_index=255)      (losses/cross_entropy_loss.py:81-86)
+//   weight_reduce_loss(mean over ALL pixels)                      (losses/utils.py:26-55)
+//   accuracy(top-1)                                               (losses/accuracy.py:38-49)
+// The [N,Cls,H,W] tensor (79.7 MB at 2x19x512x1024) is never written: each full-resolution pixel
+// interpolates its Cls logits from the 4 neighbouring low-resolution pixels (L1/L2 resident).
+// Backward is a gather: one workgroup per low-resolution logit pixel walks its bilinear footprint
+// and reduces in a fixed order (bit-reproducible, no float atomics).
+#include <algorithm>
+#include "common.h"
+#include "resize.h"
+
+namespace gs {
+
+struct CeArgs {
+  gs_ce_desc d;
+  float sh, sw;
+};
+
+// the four neighbour pointers + weights of full-resolution pixel (n, Y, X)
+struct Taps {
+  const float* p00; const float* p01; const float* p10; const float* p11;
+  float w00, w01, w10, w11;
+};
+__device__ __forceinline__ Taps make_taps(const CeArgs& a, const float* logits, int n, int Y, int X) {
+  const Lerp ly = lerp_coord(Y, a.sh, a.d.h, a.d.align_corners);
+  const Lerp lx = lerp_coord(X, a.sw, a.d.w, a.d.align_corners);
+  const float* b = logits + (long)n * a.d.l_sn;
+  Taps t;
+  t.p00 = b + ly.i0 * a.d.l_sh + lx.i0 * a.d.l_sw;
+  t.p01 = b + ly.i0 * a.d.l_sh + lx.i1 * a.d.l_sw;
+  t.p10 = b + ly.i1 * a.d.l_sh + lx.i0 * a.d.l_sw;
+  t.p11 = b + ly.i1 * a.d.l_sh + lx.i1 * a.d.l_sw;
+  t.w00 = lx.l0; t.w01 = lx.l1; t.w10 = ly.l0; t.w11 = ly.l1;  // (x weights, y weights)
+  return t;
+}
+// same association order as ATen: h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11)
+__device__ __forceinline__ float tap_value(const Taps& t, long coff) {
+  return t.w10 * (t.w00 * t.p00[coff] + t.w01 * t.p01[coff]) +
+         t.w11 * (t.w00 * t.p10[coff] + t.w01 * t.p11[coff]);
+}
+
+// mode 0: loss/acc partial sums (+ optional lse)   mode 1: prob of the label (OHEM)
+template <int MODE>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const CeArgs a, const float* __restrict__ logits,
+                                                     const int64_t* __restrict__ labels,
+                                                     const float* __restrict__ pw,
+                                                     const float* __restrict__ cw,
+                                                     float* __restrict__ lse_out,
+                                                     double* __restrict__ part,
+                                                     float* __restrict__ prob_out) {
+  const long total = (long)a.d.N * a.d.H * a.d.W;
+  double loss = 0.0, correct = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % a.d.W);
+    const long r = i / a.d.W;
+    const int Y = (int)(r % a.d.H);
+    const int n = (int)(r / a.d.H);
+    const Taps t = make_taps(a, logits, n, Y, X);
+    const long lab = labels[i];
+    const bool valid = lab != a.d.ignore_index && lab >= 0 && lab < a.d.Cls;
+    float m = -__builtin_huge_valf(), s = 0.f, zl = 0.f;
+    int amax = 0;
+    for (int c = 0; c < a.d.Cls; ++c) {
+      const float z = tap_value(t, (long)c * a.d.l_sc);
+      if (c == lab) zl = z;
+      if (z > m) {
+        s = s * expf(m - z) + 1.f;
+        m = z;
+        amax = c;
+      } else {
+        s += expf(z - m);
+      }
+    }
+    const float lse = m + logf(s);
+    if (MODE == 0) {
+      if (lse_out) lse_out[i] = lse;
+      if (valid) {
+        float l = lse - zl;
+        if (cw) l *= cw[lab];
+        if (pw) l *= pw[i];
+        loss += (double)l;
+      }
+      if ((long)amax == lab) correct += 1.0;
+    } else {
+      prob_out[i] = valid ? expf(zl - lse) : 2.0f;
+    }
+  }
+  if (MODE == 0) {
+    __shared__ double sh[8];
+    loss = wave_sum_d(loss);
+    correct = wave_sum_d(correct);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[wave] = loss; sh[4 + wave] = correct; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      part[2 * blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+      part[2 * blockIdx.x + 1] = sh[4] + sh[5] + sh[6] + sh[7];
+    }
+  }
+}
+
+__global__ void ce_final_kernel(const double* __restrict__ part, int nparts, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double l = 0.0, c = 0.0;
+    for (int p = 0; p < nparts; ++p) { l += part[2 * p]; c += part[2 * p + 1]; }
+    out[0] = l;
+    out[1] = c;
+  }
+}
+
+// One workgroup per low-resolution pixel (n, y, x); classes in chunks of CCH kept in registers.
+constexpr int CCH = 32;
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const CeArgs a, const float* __restrict__ logits,
+                                                     const int64_t* __restrict__ labels,
+                                                     const float* __restrict__ pw,
+                                                     const float* __restrict__ cw,
+                                                     const float* __restrict__ lse, float gscale,
+                                                     float* __restrict__ dlogits, int ld_d) {
+  __shared__ float sh[4][CCH];
+  const int x = blockIdx.x % a.d.w;
+  const int r = blockIdx.x / a.d.w;
+  const int y = r % a.d.h;
+  const int n = r / a.d.h;
+  int ylo, yhi, xlo, xhi;
+  dst_range(y, a.sh, a.d.H, ylo, yhi);
+  dst_range(x, a.sw, a.d.W, xlo, xhi);
+  const int nx = xhi - xlo + 1, npx = (yhi - ylo + 1) * nx;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* orow = dlogits + ((long)(n * a.d.h + y) * a.d.w + x) * ld_d;
+
+  for (int c0 = 0; c0 < a.d.Cls; c0 += CCH) {
+    const int nc = min(CCH, a.d.Cls - c0);
+    float acc[CCH];
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) acc[c] = 0.f;
+    for (int q = threadIdx.x; q < npx; q += 256) {
+      const int Y = ylo + q / nx, X = xlo + q % nx;
+      const Lerp ly = lerp_coord(Y, a.sh, a.d.h, a.d.align_corners);
+      const Lerp lx = lerp_coord(X, a.sw, a.d.w, a.d.align_corners);
+      const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
+      const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
+      const float wgt = wy * wx;
+      if (wgt == 0.f) continue;
+      const long pi = ((long)n * a.d.H + Y) * a.d.W + X;
+      const long lab = labels[pi];
+      const bool valid = lab != a.d.ignore_index && lab >= 0 && lab < a.d.Cls;
+      if (!valid) continue;
+      float coef = wgt * gscale;
+      if (cw) coef *= cw[lab];
+      if (pw) coef *= pw[pi];
+      if (coef == 0.f) continue;
+      const float l = lse[pi];
+      const float* b = logits + (long)n * a.d.l_sn;
+      Taps t;
+      t.p00 = b + ly.i0 * a.d.l_sh + lx.i0 * a.d.l_sw;
+      t.p01 = b + ly.i0 * a.d.l_sh + lx.i1 * a.d.l_sw;
+      t.p10 = b + ly.i1 * a.d.l_sh + lx.i0 * a.d.l_sw;
+      t.p11 = b + ly.i1 * a.d.l_sh + lx.i1 * a.d.l_sw;
+      t.w00 = lx.l0; t.w01 = lx.l1; t.w10 = ly.l0; t.w11 = ly.l1;
+#pragma unroll
+      for (int c = 0; c < CCH; ++c) {
+        if (c < nc) {
+          const float z = tap_value(t, (long)(c0 + c) * a.d.l_sc);
+          float p = expf(z - l);
+          if (c0 + c == lab) p -= 1.f;
+          acc[c] += coef * p;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) {
+      const float v = wave_sum(acc[c]);
+      if (lane == 0) sh[wave][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < CCH && threadIdx.x < nc)
+      orow[c0 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] +
+                               sh[3][threadIdx.x];
+    __syncthreads();
+  }
+  // zero the padding columns Cls..ld_d-1
+  for (int c = a.d.Cls + threadIdx.x; c < ld_d; c += 256) orow[c] = 0.f;
+}
+
+// argmax (and optional softmax probabilities) of the resized logits
+__global__ __launch_bounds__(256) void resize_argmax_kernel(const CeArgs a,
+                                                            const float* __restrict__ logits,
+                                                            int64_t* __restrict__ seg,
+                                                            float* __restrict__ probs) {
+  const long total = (long)a.d.N * a.d.H * a.d.W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % a.d.W);
+    const long r = i / a.d.W;
+    const int Y = (int)(r % a.d.H);
+    const int n = (int)(r / a.d.H);
+    const Taps t = make_taps(a, logits, n, Y, X);
+    float m = -__builtin_huge_valf(), s = 0.f;
+    int amax = 0;
+    for (int c = 0; c < a.d.Cls; ++c) {
+      const float z = tap_value(t, (long)c * a.d.l_sc);
+      if (z > m) { s = s * expf(m - z) + 1.f; m = z; amax = c; }
+      else s += expf(z - m);
+    }
+    if (seg) seg[i] = amax;
+    if (probs) {
+      const float inv = 1.f / s;
+      for (int c = 0; c < a.d.Cls; ++c)
+        probs[i * a.d.Cls + c] = expf(tap_value(t, (long)c * a.d.l_sc) - m) * inv;
+    }
+  }
+}
+
+static int check_ce(const gs_ce_desc* d, CeArgs& a) {
+  if (!d) return GS_E_NULL;
+  if (d->N <= 0 || d->h <= 0 || d->w <= 0 || d->Cls <= 0 || d->H <= 0 || d->W <= 0)
+    return GS_E_BADARG;
+  a.d = *d;
+  a.sh = resize_scale(d->h, d->H, d->align_corners);
+  a.sw = resize_scale(d->w, d->W, d->align_corners);
+  return GS_OK;
+}
+static int ce_grid(const gs_ce_desc* d) {
+  return stream_grid((long)d->N * d->H * d->W, 256);
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" size_t gs_ce_workspace_bytes(const gs_ce_desc* d) {
+  CeArgs a;
+  if (check_ce(d, a)) return 0;
+  return (size_t)ce_grid(d) * 2 * sizeof(double);
+}
+
+extern "C" int gs_ce_forward(const gs_ce_desc* d, const float* logits, const int64_t* labels,
+                             const float* pixel_weight, const float* class_weight, float* lse,
+                             double* out, void* workspace, size_t workspace_bytes, void* stream) {
+  CeArgs a;
+  int rc = check_ce(d, a);
+  if (rc) return rc;
+  if (!logits || !labels || !out || !workspace) return GS_E_NULL;
+  const int grid = ce_grid(d);
+  if ((size_t)grid * 2 * sizeof(double) > workspace_bytes) return GS_E_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 7) return GS_E_ALIGN;
+  hipStream_t st = as_stream(stream);
+  double* part = static_cast<double*>(workspace);
+  hipLaunchKernelGGL(ce_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, a, logits, labels,
+                     pixel_weight, class_weight, lse, part, (float*)nullptr);
+  hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(64), 0, st, part, grid, out);
+  return launch_status();
+}
+
+extern "C" int gs_ce_backward(const gs_ce_desc* d, const float* logits, const int64_t* labels,
+                              const float* pixel_weight, const float* class_weight,
+                              const float* lse, float grad_scale, float* dlogits, int32_t ld_d,
+                              void* stream) {
+  CeArgs a;
+  int rc = check_ce(d, a);
+  if (rc) return rc;
+  if (!logits || !labels || !lse || !dlogits) return GS_E_NULL;
+  if (ld_d < d->Cls) return GS_E_BADARG;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(d->N * d->h * d->w), dim3(256), 0, as_stream(stream), a,
+                     logits, labels, pixel_weight, class_weight, lse, grad_scale, dlogits, ld_d);
+  return launch_status();
+}
+
+extern "C" int gs_ce_label_prob(const gs_ce_desc* d, const float* logits, const int64_t* labels,
+                                float* prob, void* stream) {
+  CeArgs a;
+  int rc = check_ce(d, a);
+  if (rc) return rc;
+  if (!logits || !labels || !prob) return GS_E_NULL;
+  hipLaunchKernelGGL(ce_fwd_kernel<1>, dim3(ce_grid(d)), dim3(256), 0, as_stream(stream), a, logits,
+                     labels, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                     (double*)nullptr, prob);
+  return launch_status();
+}
+
+extern "C" int gs_resize_argmax(const gs_ce_desc* d, const float* logits, int64_t* seg,
+                                float* probs, void* stream) {
+  CeArgs a;
+  int rc = check_ce(d, a);
+  if (rc) return rc;
+  if (!logits || (!seg && !probs)) return GS_E_NULL;
+  hipLaunchKernelGGL(resize_argmax_kernel, dim3(ce_grid(d)), dim3(256), 0, as_stream(stream), a,
+                     logits, seg, probs);
+  return launch_status();
+}

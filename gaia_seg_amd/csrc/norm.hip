@@ -1,0 +1,469 @@
+// Dynamic BatchNorm (+residual add, +ReLU) for NHWC fp32 activations on gfx950 — HBM-bound.
+//
+// Replaces F.batch_norm over the leading C-slice of the max-size DynBN / DynSyncBN parameters
+// (call sites gaiaseg/models/backbones/dynamic_resnet.py:267-300,411,
+// gaiaseg/models/utils/dynamic_res_layer.py:92 and the norm1-3 of gaiavision DynamicBottleneck),
+// the following ReLU(inplace) and the bottleneck's `out += identity; relu`.
+//
+// All kernels use one thread->(row, channel-quad) map: a 256-thread block covers `rpi` whole
+// rows of C/4 float4 per iteration, so a thread keeps its channel quad for the whole loop
+// (per-channel accumulators live in registers) and every wave reads contiguous 16 B/lane.
+// Reductions are two-level with a fixed summation order (block partials -> one thread per
+// channel), hence bit-reproducible run to run.
+#include <algorithm>
+#include "common.h"
+
+namespace gs {
+
+struct ColMap {
+  int cq;        // channel quad handled by this thread (float4 index within a row)
+  int rr;        // row offset within an iteration
+  int rpi;       // rows per iteration
+  bool active;
+};
+
+// C4 = C/4.  When C4 <= 256 one block covers all channels (blockIdx.y == 0) and several rows
+// per iteration; otherwise blockIdx.y walks 256-quad column blocks and rpi == 1.
+__device__ __forceinline__ ColMap col_map(int C4) {
+  ColMap m;
+  const int t = threadIdx.x;
+  if (C4 <= 256) {
+    m.rpi = 256 / C4;
+    m.rr = t / C4;
+    m.cq = t - m.rr * C4;
+    m.active = m.rr < m.rpi;
+  } else {
+    m.rpi = 1;
+    m.rr = 0;
+    m.cq = blockIdx.y * 256 + t;
+    m.active = m.cq < C4;
+  }
+  return m;
+}
+
+// Block reduction of two float4 accumulators over the rr dimension; result valid for rr == 0.
+__device__ __forceinline__ void block_reduce_rows(f32x4& a, f32x4& b, const ColMap& m, int C4,
+                                                  f32x4* sh /* [2*256] */) {
+  if (m.rpi == 1) return;
+  const int t = threadIdx.x;
+  sh[t] = a;
+  sh[256 + t] = b;
+  __syncthreads();
+  if (m.active && m.rr == 0) {
+    for (int r = 1; r < m.rpi; ++r) {
+      a += sh[r * C4 + m.cq];
+      b += sh[256 + r * C4 + m.cq];
+    }
+  }
+}
+
+// ---------------- forward statistics ----------------
+// part[blockIdx.x][2][C] : shifted sums over this block's row range.
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x,
+                                                               long rows, int C, int ldx,
+                                                               long rows_per_block,
+                                                               float* __restrict__ part) {
+  __shared__ f32x4 sh[512];
+  const int C4 = C >> 2;
+  const ColMap m = col_map(C4);
+  f32x4 s1{0.f, 0.f, 0.f, 0.f}, s2{0.f, 0.f, 0.f, 0.f};
+  if (m.active) {
+    const f32x4 shift = *reinterpret_cast<const f32x4*>(x + m.cq * 4);  // row 0
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(r0 + rows_per_block, rows);
+    for (long r = r0 + m.rr; r < r1; r += m.rpi) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + m.cq * 4) - shift;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  block_reduce_rows(s1, s2, m, C4, sh);
+  if (m.active && m.rr == 0) {
+    float* o = part + (long)blockIdx.x * 2 * C;
+    *reinterpret_cast<f32x4*>(o + m.cq * 4) = s1;
+    *reinterpret_cast<f32x4*>(o + C + m.cq * 4) = s2;
+  }
+}
+
+// sums[0..C) = S1, [C..2C) = S2, [2C..3C) = shift  (fixed-order sum over the partials)
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ part,
+                                                             int nparts, int C,
+                                                             const float* __restrict__ x,
+                                                             float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s1 += part[(long)p * 2 * C + c];
+    s2 += part[(long)p * 2 * C + C + c];
+  }
+  sums[c] = (float)s1;
+  sums[C + c] = (float)s2;
+  sums[2 * C + c] = x[c];
+}
+
+// coeffs: [0,C) scale = gamma*invstd ; [C,2C) beta ; [2C,3C) mean ; [3C,4C) invstd
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums,
+                                                          double count, int C,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float momentum, float* running_mean,
+                                                          float* running_var,
+                                                          float* __restrict__ coeffs) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double d1 = (double)sums[c] / count;
+  const double mean = (double)sums[2 * C + c] + d1;
+  double var = (double)sums[C + c] / count - d1 * d1;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const float g = gamma ? gamma[c] : 1.f;
+  coeffs[c] = (float)((double)g * invstd);
+  coeffs[C + c] = beta ? beta[c] : 0.f;
+  coeffs[2 * C + c] = (float)mean;
+  coeffs[3 * C + c] = (float)invstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(const float* __restrict__ rm,
+                                                             const float* __restrict__ rv, int C,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             float eps, float* __restrict__ coeffs) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double invstd = 1.0 / sqrt((double)rv[c] + (double)eps);
+  const float g = gamma ? gamma[c] : 1.f;
+  coeffs[c] = (float)((double)g * invstd);
+  coeffs[C + c] = beta ? beta[c] : 0.f;
+  coeffs[2 * C + c] = rm[c];
+  coeffs[3 * C + c] = (float)invstd;
+}
+
+// y = act((x - mean) * scale + beta (+ residual))
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, long rows, int C, int ldx,
+                                                       const float* __restrict__ coeffs,
+                                                       const float* res, int ld_res, float* y,
+                                                       int ldy) {  // x / res / y may alias
+  const int C4 = C >> 2;
+  const ColMap m = col_map(C4);
+  if (!m.active) return;
+  const f32x4 scale = *reinterpret_cast<const f32x4*>(coeffs + m.cq * 4);
+  const f32x4 beta = *reinterpret_cast<const f32x4*>(coeffs + C + m.cq * 4);
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(coeffs + 2 * C + m.cq * 4);
+  const long step = (long)gridDim.x * m.rpi;
+  for (long r = (long)blockIdx.x * m.rpi + m.rr; r < rows; r += step) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + m.cq * 4);
+    v = (v - mean) * scale + beta;
+    if (RES) v += *reinterpret_cast<const f32x4*>(res + r * ld_res + m.cq * 4);
+    if (RELU) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+      v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(y + r * ldy + m.cq * 4) = v;
+  }
+}
+
+// ---------------- backward ----------------
+template <int MASK>
+__device__ __forceinline__ f32x4 masked_grad(f32x4 dy, f32x4 x, f32x4 act, f32x4 mean, f32x4 scale,
+                                             f32x4 beta) {
+  if (MASK == 1) {
+    const f32x4 yv = (x - mean) * scale + beta;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dy[e] = yv[e] > 0.f ? dy[e] : 0.f;
+  } else if (MASK == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dy[e] = act[e] > 0.f ? dy[e] : 0.f;
+  }
+  return dy;
+}
+
+// part[blockIdx.x][2][C] = { sum g, sum g*xhat } ; optionally writes g (masked dy)
+template <int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(
+    const float* __restrict__ dy, int ld_dy, const float* __restrict__ x, int ldx,
+    const float* __restrict__ act, int ld_act, long rows, int C, const float* __restrict__ coeffs,
+    long rows_per_block, float* g_out, int ld_g, float* __restrict__ part) {
+  __shared__ f32x4 sh[512];
+  const int C4 = C >> 2;
+  const ColMap m = col_map(C4);
+  f32x4 s1{0.f, 0.f, 0.f, 0.f}, s2{0.f, 0.f, 0.f, 0.f};
+  if (m.active) {
+    const f32x4 scale = *reinterpret_cast<const f32x4*>(coeffs + m.cq * 4);
+    const f32x4 beta = *reinterpret_cast<const f32x4*>(coeffs + C + m.cq * 4);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(coeffs + 2 * C + m.cq * 4);
+    const f32x4 invstd = *reinterpret_cast<const f32x4*>(coeffs + 3 * C + m.cq * 4);
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(r0 + rows_per_block, rows);
+    for (long r = r0 + m.rr; r < r1; r += m.rpi) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ldx + m.cq * 4);
+      f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * ld_dy + m.cq * 4);
+      f32x4 av{0.f, 0.f, 0.f, 0.f};
+      if (MASK == 2) av = *reinterpret_cast<const f32x4*>(act + r * ld_act + m.cq * 4);
+      g = masked_grad<MASK>(g, xv, av, mean, scale, beta);
+      if (g_out) *reinterpret_cast<f32x4*>(g_out + r * ld_g + m.cq * 4) = g;
+      s1 += g;
+      s2 += g * ((xv - mean) * invstd);
+    }
+  }
+  block_reduce_rows(s1, s2, m, C4, sh);
+  if (m.active && m.rr == 0) {
+    float* o = part + (long)blockIdx.x * 2 * C;
+    *reinterpret_cast<f32x4*>(o + m.cq * 4) = s1;
+    *reinterpret_cast<f32x4*>(o + C + m.cq * 4) = s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part,
+                                                           int nparts, int width,
+                                                           float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= width) return;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += part[(long)p * width + c];
+  out[c] = (float)s;
+}
+
+// dx = scale * (g - sum_g/n - xhat*sum_gx/n)  or  dx = scale*g (eval-mode statistics)
+template <int MASK, bool BATCH>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dy, int ld_dy, const float* __restrict__ x, int ldx,
+    const float* __restrict__ act, int ld_act, long rows, int C, const float* __restrict__ coeffs,
+    const float* __restrict__ sums, float inv_count, float* __restrict__ dx, int ld_dx,
+    float* dgamma, float* dbeta) {
+  const int C4 = C >> 2;
+  const ColMap m = col_map(C4);
+  if (!m.active) return;
+  const f32x4 scale = *reinterpret_cast<const f32x4*>(coeffs + m.cq * 4);
+  const f32x4 beta = *reinterpret_cast<const f32x4*>(coeffs + C + m.cq * 4);
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(coeffs + 2 * C + m.cq * 4);
+  const f32x4 invstd = *reinterpret_cast<const f32x4*>(coeffs + 3 * C + m.cq * 4);
+  const f32x4 sg = *reinterpret_cast<const f32x4*>(sums + m.cq * 4);
+  const f32x4 sgx = *reinterpret_cast<const f32x4*>(sums + C + m.cq * 4);
+  if (blockIdx.x == 0 && m.rr == 0) {
+    if (dgamma) *reinterpret_cast<f32x4*>(dgamma + m.cq * 4) = sgx;
+    if (dbeta) *reinterpret_cast<f32x4*>(dbeta + m.cq * 4) = sg;
+  }
+  const f32x4 c1 = sg * inv_count, c2 = sgx * inv_count;
+  const long step = (long)gridDim.x * m.rpi;
+  for (long r = (long)blockIdx.x * m.rpi + m.rr; r < rows; r += step) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ldx + m.cq * 4);
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * ld_dy + m.cq * 4);
+    f32x4 av{0.f, 0.f, 0.f, 0.f};
+    if (MASK == 2) av = *reinterpret_cast<const f32x4*>(act + r * ld_act + m.cq * 4);
+    g = masked_grad<MASK>(g, xv, av, mean, scale, beta);
+    f32x4 o;
+    if (BATCH) o = scale * (g - c1 - ((xv - mean) * invstd) * c2);
+    else o = scale * g;
+    *reinterpret_cast<f32x4*>(dx + r * ld_dx + m.cq * 4) = o;
+  }
+}
+
+// plain per-column sums (conv_seg bias gradient)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long rows,
+                                                             int C, int ldx, long rows_per_block,
+                                                             float* __restrict__ part) {
+  __shared__ f32x4 sh[512];
+  const int C4 = C >> 2;
+  const ColMap m = col_map(C4);
+  f32x4 s1{0.f, 0.f, 0.f, 0.f}, s2{0.f, 0.f, 0.f, 0.f};
+  if (m.active) {
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(r0 + rows_per_block, rows);
+    for (long r = r0 + m.rr; r < r1; r += m.rpi)
+      s1 += *reinterpret_cast<const f32x4*>(x + r * ldx + m.cq * 4);
+  }
+  block_reduce_rows(s1, s2, m, C4, sh);
+  if (m.active && m.rr == 0)
+    *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * C + m.cq * 4) = s1;
+}
+
+// ---- host helpers ----
+struct RedGeom {
+  int gx, gy;
+  long rows_per_block;
+};
+static RedGeom red_geom(long rows, int C) {
+  const int C4 = C >> 2;
+  RedGeom g;
+  g.gy = C4 <= 256 ? 1 : (int)ceil_div(C4, 256);
+  const int rpi = C4 <= 256 ? 256 / C4 : 1;
+  // ~4 iterations per block at least, at most 1024 row blocks (partials stay small)
+  long gx = ceil_div(rows, (long)rpi * 4);
+  const long cap = std::max<long>(1, 1024 / g.gy);
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  g.rows_per_block = ceil_div(rows, gx);
+  // keep whole iterations inside a block so the rr lanes stay balanced
+  g.rows_per_block = ceil_div(g.rows_per_block, rpi) * rpi;
+  g.gx = (int)ceil_div(rows, g.rows_per_block);
+  return g;
+}
+static int apply_grid(long rows, int C) {
+  const int C4 = C >> 2;
+  const int rpi = C4 <= 256 ? 256 / C4 : 1;
+  long gx = ceil_div(rows, (long)rpi * 2);
+  const long cap = (long)kNumCU * 8;
+  if (gx > cap) gx = cap;
+  return (int)std::max<long>(gx, 1);
+}
+static int check_rows(const void* p, long rows, int C, int ld) {
+  if (!p) return GS_E_NULL;
+  if (rows <= 0 || C <= 0) return GS_E_BADARG;
+  if ((C & 3) || (ld & 3) || ld < C || !aligned16(p)) return GS_E_ALIGN;
+  return GS_OK;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" size_t gs_bn_stats_workspace_bytes(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0 || (C & 3)) return 0;
+  const RedGeom g = red_geom(rows, C);
+  return (size_t)g.gx * 2 * C * sizeof(float);
+}
+extern "C" size_t gs_bn_bwd_workspace_bytes(int64_t rows, int32_t C) {
+  return gs_bn_stats_workspace_bytes(rows, C);
+}
+extern "C" size_t gs_colsum_workspace_bytes(int64_t rows, int32_t C) {
+  return gs_bn_stats_workspace_bytes(rows, C);
+}
+
+extern "C" int gs_bn_stats(const float* x, int64_t rows, int32_t C, int32_t ldx, float* sums,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_rows(x, rows, C, ldx);
+  if (rc) return rc;
+  if (!sums || !workspace) return GS_E_NULL;
+  const RedGeom g = red_geom(rows, C);
+  if ((size_t)g.gx * 2 * C * sizeof(float) > workspace_bytes) return GS_E_WORKSPACE;
+  if (!aligned16(workspace)) return GS_E_ALIGN;
+  hipStream_t st = as_stream(stream);
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(g.gx, g.gy), dim3(256), 0, st, x, (long)rows, C,
+                     ldx, g.rows_per_block, part);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, g.gx, C,
+                     x, sums);
+  return launch_status();
+}
+
+extern "C" int gs_bn_finalize(const float* sums, double count, int32_t C, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean,
+                              float* running_var, float* coeffs, void* stream) {
+  if (!sums || !coeffs) return GS_E_NULL;
+  if (C <= 0 || count <= 0.0) return GS_E_BADARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream),
+                     sums, count, C, gamma, beta, eps, momentum, running_mean, running_var, coeffs);
+  return launch_status();
+}
+
+extern "C" int gs_bn_eval_coeffs(const float* running_mean, const float* running_var, int32_t C,
+                                 const float* gamma, const float* beta, float eps, float* coeffs,
+                                 void* stream) {
+  if (!running_mean || !running_var || !coeffs) return GS_E_NULL;
+  if (C <= 0) return GS_E_BADARG;
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream),
+                     running_mean, running_var, C, gamma, beta, eps, coeffs);
+  return launch_status();
+}
+
+extern "C" int gs_bn_apply(const float* x, int64_t rows, int32_t C, int32_t ldx,
+                           const float* coeffs, const float* residual, int32_t ld_res,
+                           int32_t relu, float* y, int32_t ldy, void* stream) {
+  int rc = check_rows(x, rows, C, ldx);
+  if (rc) return rc;
+  rc = check_rows(y, rows, C, ldy);
+  if (rc) return rc;
+  if (!coeffs) return GS_E_NULL;
+  if (!aligned16(coeffs)) return GS_E_ALIGN;
+  if (residual && (rc = check_rows(residual, rows, C, ld_res))) return rc;
+  const dim3 grid(apply_grid(rows, C), (C >> 2) <= 256 ? 1 : (unsigned)ceil_div(C >> 2, 256));
+  hipStream_t st = as_stream(stream);
+#define GS_APPLY(R, A)                                                                          \
+  hipLaunchKernelGGL((bn_apply_kernel<R, A>), grid, dim3(256), 0, st, x, (long)rows, C, ldx,    \
+                     coeffs, residual, ld_res, y, ldy)
+  if (residual) { if (relu) GS_APPLY(true, true); else GS_APPLY(true, false); }
+  else { if (relu) GS_APPLY(false, true); else GS_APPLY(false, false); }
+#undef GS_APPLY
+  return launch_status();
+}
+
+extern "C" int gs_bn_bwd_reduce(const float* dy, int32_t ld_dy, const float* x, int32_t ldx,
+                                const float* act, int32_t ld_act, int64_t rows, int32_t C,
+                                const float* coeffs, int32_t mask_mode, float* g_out, int32_t ld_g,
+                                float* sums, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  int rc = check_rows(dy, rows, C, ld_dy);
+  if (rc) return rc;
+  if ((rc = check_rows(x, rows, C, ldx))) return rc;
+  if (mask_mode < 0 || mask_mode > 2) return GS_E_BADARG;
+  if (mask_mode == 2 && (rc = check_rows(act, rows, C, ld_act))) return rc;
+  if (g_out && (rc = check_rows(g_out, rows, C, ld_g))) return rc;
+  if (!coeffs || !sums || !workspace) return GS_E_NULL;
+  if (!aligned16(coeffs) || !aligned16(workspace)) return GS_E_ALIGN;
+  const RedGeom g = red_geom(rows, C);
+  if ((size_t)g.gx * 2 * C * sizeof(float) > workspace_bytes) return GS_E_WORKSPACE;
+  hipStream_t st = as_stream(stream);
+  float* part = static_cast<float*>(workspace);
+#define GS_BWDP(MK)                                                                             \
+  hipLaunchKernelGGL((bn_bwd_partial_kernel<MK>), dim3(g.gx, g.gy), dim3(256), 0, st, dy, ld_dy, \
+                     x, ldx, act, ld_act, (long)rows, C, coeffs, g.rows_per_block, g_out, ld_g, part)
+  if (mask_mode == 0) GS_BWDP(0); else if (mask_mode == 1) GS_BWDP(1); else GS_BWDP(2);
+#undef GS_BWDP
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, part, g.gx,
+                     2 * C, sums);
+  return launch_status();
+}
+
+extern "C" int gs_bn_bwd_apply(const float* dy, int32_t ld_dy, const float* x, int32_t ldx,
+                               const float* act, int32_t ld_act, int64_t rows, int32_t C,
+                               const float* coeffs, const float* sums, double count,
+                               int32_t mask_mode, int32_t use_batch_stats, float* dx,
+                               int32_t ld_dx, float* dgamma, float* dbeta, void* stream) {
+  int rc = check_rows(dy, rows, C, ld_dy);
+  if (rc) return rc;
+  if ((rc = check_rows(x, rows, C, ldx))) return rc;
+  if ((rc = check_rows(dx, rows, C, ld_dx))) return rc;
+  if (mask_mode < 0 || mask_mode > 2 || count <= 0.0) return GS_E_BADARG;
+  if (mask_mode == 2 && (rc = check_rows(act, rows, C, ld_act))) return rc;
+  if (!coeffs || !sums) return GS_E_NULL;
+  if (!aligned16(coeffs) || !aligned16(sums) || (dgamma && !aligned16(dgamma)) ||
+      (dbeta && !aligned16(dbeta)))
+    return GS_E_ALIGN;
+  const dim3 grid(apply_grid(rows, C), (C >> 2) <= 256 ? 1 : (unsigned)ceil_div(C >> 2, 256));
+  hipStream_t st = as_stream(stream);
+  const float inv = (float)(1.0 / count);
+#define GS_BWDA(MK, B)                                                                           \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, B>), grid, dim3(256), 0, st, dy, ld_dy, x, ldx, act, \
+                     ld_act, (long)rows, C, coeffs, sums, inv, dx, ld_dx, dgamma, dbeta)
+  if (use_batch_stats) {
+    if (mask_mode == 0) GS_BWDA(0, true); else if (mask_mode == 1) GS_BWDA(1, true); else GS_BWDA(2, true);
+  } else {
+    if (mask_mode == 0) GS_BWDA(0, false); else if (mask_mode == 1) GS_BWDA(1, false); else GS_BWDA(2, false);
+  }
+#undef GS_BWDA
+  return launch_status();
+}
+
+extern "C" int gs_colsum(const float* src, int64_t rows, int32_t C, int32_t ld, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_rows(src, rows, C, ld);
+  if (rc) return rc;
+  if (!out || !workspace) return GS_E_NULL;
+  const RedGeom g = red_geom(rows, C);
+  if ((size_t)g.gx * C * sizeof(float) > workspace_bytes) return GS_E_WORKSPACE;
+  if (!aligned16(workspace)) return GS_E_ALIGN;
+  hipStream_t st = as_stream(stream);
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(g.gx, g.gy), dim3(256), 0, st, src, (long)rows, C,
+                     ld, g.rows_per_block, part);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, g.gx, C,
+                     out);
+  return launch_status();
+}

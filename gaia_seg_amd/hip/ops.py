@@ -1,0 +1,440 @@
+"""Tape-aware operators: each function launches the forward HIP kernel(s) through the C-ABI and
+records the closure that launches the backward kernel(s).
+
+Nothing in this file computes with torch ops on the data path; torch is used for allocation,
+stream handles and (SyncBN only) the tiny statistics exchange over RCCL.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+from .runtime import WORKSPACE, Act, current_stream_ptr, round_up
+
+_ws = WORKSPACE
+
+
+def _L():
+    return _lib.load()
+
+
+def ensure_grad(param):
+    """``param.grad`` with the physical layout of ``param`` (zeros on first use).
+
+    Parameters with a padded / permuted physical layout (HWIO conv weights, the padded conv_seg
+    bias) carry a ``_gs_grad_factory`` that allocates matching storage; with a ParamArena installed
+    the gradients already exist as views of the flat gradient buffer."""
+    if param.grad is None:
+        factory = getattr(param, "_gs_grad_factory", None)
+        if factory is not None:
+            param.grad = factory()
+        else:
+            param.grad = torch.zeros_like(param, memory_format=torch.preserve_format)
+    if param.grad.stride() != param.stride():
+        raise RuntimeError("gradient layout %s differs from parameter layout %s"
+                           % (param.grad.stride(), param.stride()))
+    return param.grad
+
+
+def _notify(param):
+    hook = getattr(param, "_gs_grad_ready", None)
+    if hook is not None:
+        hook(param)
+
+
+def conv_out_size(h, k, s, p, d):
+    return (h + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def _conv_desc(x, weight, co, stride, pad, dil, ldy, ld_add=0):
+    """gs_conv_desc for activation ``x`` and a max-size weight Parameter (logical OIHW, physical
+    HWIO with row pitch ``Co_ld``)."""
+    co_max, ci_max, kh, kw = weight.shape
+    co_ld = weight.stride(1)
+    d = _lib.ConvDesc()
+    if x.nchw_image:
+        n, c, h, w = x.t.shape
+        d.x_sn, d.x_sc, d.x_sh, d.x_sw = x.t.stride()
+    else:
+        n, h, w, c = x.t.shape
+        d.x_sn, d.x_sh, d.x_sw, d.x_sc = x.t.stride()
+    d.N, d.H, d.W, d.Ci, d.Co = n, h, w, c, co
+    d.Ci_max, d.Co_ld, d.KH, d.KW = ci_max, co_ld, kh, kw
+    d.stride, d.pad, d.dil = stride, pad, dil
+    d.Ho = conv_out_size(h, kh, stride, pad, dil)
+    d.Wo = conv_out_size(w, kw, stride, pad, dil)
+    d.ldy, d.ld_add = ldy, ld_add
+    if c > ci_max:
+        raise ValueError("input has %d channels, conv supports at most %d" % (c, ci_max))
+    return d
+
+
+def conv2d(tape, x, weight, bias, co, stride=1, pad=0, dil=1, out=None):
+    """DynConv2d forward: y = conv(x, weight[:co, :x.C]) (+ bias[:co]).
+
+    ``co`` is the active output width; the active input width is x.C."""
+    L = _L()
+    co_eff = round_up(co, 4)
+    dev = x.t.device
+    kh, kw = weight.shape[2], weight.shape[3]
+    if x.nchw_image:
+        n, _, h, w = x.t.shape
+    else:
+        n, h, w, _ = x.t.shape
+    ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(w, kw, stride, pad, dil)
+    if out is None:
+        out = Act.empty(n, ho, wo, co, dev)
+    d = _conv_desc(x, weight, co_eff, stride, pad, dil, out.ld)
+    need = L.gs_conv2d_workspace_bytes(ctypes.byref(d))
+    ws = _ws.get(need, dev)
+    st = current_stream_ptr()
+    _lib.check(L.gs_conv2d_forward(ctypes.byref(d), x.ptr, weight.data_ptr(),
+                                   bias.data_ptr() if bias is not None else None, None, out.ptr,
+                                   ws.data_ptr(), ws.numel(), st), "gs_conv2d_forward")
+
+    def backward():
+        dy = out.g
+        if dy is None:
+            return
+        ws_b = _ws.get(need, dev)
+        s = current_stream_ptr()
+        if weight.requires_grad:
+            gw = ensure_grad(weight)
+            _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
+                                         ws_b.data_ptr(), ws_b.numel(), s), "gs_conv2d_wgrad")
+            _notify(weight)
+        if bias is not None and bias.requires_grad:
+            gb = ensure_grad(bias)
+            rows = out.rows
+            nb = L.gs_colsum_workspace_bytes(rows, co_eff)
+            wsb = _ws.get(nb, dev)
+            # the padded bias storage holds co_eff floats; the sum of the pad column is zero
+            _lib.check(L.gs_colsum(dy.data_ptr(), rows, co_eff, out.ld, gb.data_ptr(),
+                                   wsb.data_ptr(), wsb.numel(), s), "gs_colsum")
+            _notify(bias)
+        if x.requires_grad:
+            acc = x.g is not None
+            if not acc:
+                x.new_grad() if x.parent is None else _alloc_parent_grad(x)
+            _lib.check(L.gs_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), weight.data_ptr(),
+                                         x.g.data_ptr(), 1 if acc else 0, ws_b.data_ptr(),
+                                         ws_b.numel(), s), "gs_conv2d_dgrad")
+
+    tape.record(backward)
+    return out
+
+
+def _alloc_parent_grad(a):
+    """Gradient storage for a channel slice: allocate (zeroed) on the owning buffer."""
+    root = a
+    while root.parent is not None:
+        root = root.parent
+    if root.g is None:
+        root.new_grad().zero_()
+
+
+class BNParams:
+    """What the BN kernels need from a DynBN / SyncBN module (leading-slice semantics, A2)."""
+    __slots__ = ("weight", "bias", "running_mean", "running_var", "eps", "momentum", "training",
+                 "process_group", "num_batches_tracked")
+
+    def __init__(self, weight, bias, running_mean, running_var, eps, momentum, training,
+                 process_group=None, num_batches_tracked=None):
+        self.weight, self.bias = weight, bias
+        self.running_mean, self.running_var = running_mean, running_var
+        self.eps, self.momentum, self.training = eps, momentum, training
+        self.process_group = process_group
+        self.num_batches_tracked = num_batches_tracked
+
+
+def _sync_stats(sums, count, C, pg):
+    """SyncBN: merge per-rank (shifted sums, count) into global statistics (Chan et al.).
+
+    Mirrors torch.nn.SyncBatchNorm's all_gather of [mean, var, count]; the
+    payload is 2C+1 floats per rank."""
+    import torch.distributed as dist
+    world = dist.get_world_size(pg)
+    d1 = sums[:C].double() / count
+    mean = sums[2 * C:3 * C].double() + d1
+    var = (sums[C:2 * C].double() / count - d1 * d1).clamp_(min=0)
+    local = torch.cat([mean, var, torch.tensor([count], dtype=torch.float64, device=sums.device)])
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local, group=pg)
+    g = torch.stack(gathered)                     # [world, 2C+1]
+    cnt = g[:, 2 * C:]                            # [world, 1]
+    total = cnt.sum()
+    gmean = (g[:, :C] * cnt).sum(0) / total
+    gvar = ((g[:, C:2 * C] + (g[:, :C] - gmean) ** 2) * cnt).sum(0) / total
+    merged = torch.empty_like(sums)
+    merged[:C] = 0
+    merged[C:2 * C] = (gvar * total).float()
+    merged[2 * C:3 * C] = gmean.float()
+    return merged, float(total.item())
+
+
+def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
+    """y = act(BN(x) (+ residual)).  Training: batch statistics over N*H*W of the active slice,
+    running statistics updated on the slice; eval: running statistics.  ``inplace`` reuses x's
+    storage for y (only when x is not needed by backward, i.e. never in training)."""
+    L = _L()
+    dev = x.t.device
+    C, rows = x.C, x.rows
+    st = current_stream_ptr()
+    buf = torch.empty(7 * C, dtype=torch.float32, device=dev)
+    sums, coeffs = buf[:3 * C], buf[3 * C:]
+    gamma = bn.weight.data_ptr() if bn.weight is not None else None
+    beta = bn.bias.data_ptr() if bn.bias is not None else None
+    count = float(rows)
+    use_batch = bn.training or bn.running_mean is None
+    if use_batch:
+        if rows <= 1 and bn.process_group is None:
+            raise ValueError("Expected more than 1 value per channel when training, got input "
+                             "size %s" % (tuple(x.t.shape),))
+        nb = L.gs_bn_stats_workspace_bytes(rows, C)
+        ws = _ws.get(nb, dev)
+        _lib.check(L.gs_bn_stats(x.ptr, rows, C, x.ld, sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 st), "gs_bn_stats")
+        if bn.process_group is not None:
+            merged, count = _sync_stats(sums, count, C, bn.process_group)
+            sums = merged
+        rm = bn.running_mean.data_ptr() if (bn.running_mean is not None and bn.training) else None
+        rv = bn.running_var.data_ptr() if (bn.running_var is not None and bn.training) else None
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        _lib.check(L.gs_bn_finalize(sums.data_ptr(), count, C, gamma, beta, bn.eps, mom, rm, rv,
+                                    coeffs.data_ptr(), st), "gs_bn_finalize")
+        if bn.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+    else:
+        _lib.check(L.gs_bn_eval_coeffs(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), C,
+                                       gamma, beta, bn.eps, coeffs.data_ptr(), st),
+                   "gs_bn_eval_coeffs")
+    if out is None:
+        out = x if (inplace and not tape.enabled) else Act.empty(x.N, x.H, x.W, C, dev)
+    _lib.check(L.gs_bn_apply(x.ptr, rows, C, x.ld, coeffs.data_ptr(),
+                             residual.ptr if residual is not None else None,
+                             residual.ld if residual is not None else 0, 1 if relu else 0,
+                             out.ptr, out.ld, st), "gs_bn_apply")
+
+    def backward():
+        dy = out.g
+        if dy is None:
+            return
+        s = current_stream_ptr()
+        mask = 0 if not relu else (2 if residual is not None else 1)
+        nbw = L.gs_bn_bwd_workspace_bytes(rows, C)
+        wsb = _ws.get(nbw, dev)
+        bsums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        # the masked gradient g is also the gradient of the identity branch: write it in place
+        want_g = residual is not None and residual.requires_grad and relu
+        _lib.check(L.gs_bn_bwd_reduce(dy.data_ptr(), dy.stride(2),
+                                      x.ptr, x.ld, out.ptr, out.ld, rows, C, coeffs.data_ptr(),
+                                      mask, dy.data_ptr() if want_g else None, dy.stride(2),
+                                      bsums.data_ptr(), wsb.data_ptr(), wsb.numel(), s),
+                   "gs_bn_bwd_reduce")
+        bcount = count
+        if use_batch and bn.process_group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(bsums, group=bn.process_group)
+        mask_apply = 0 if want_g else mask  # dy already masked in place
+        wgrad = bn.weight is not None and bn.weight.requires_grad
+        bgrad = bn.bias is not None and bn.bias.requires_grad
+        gw = ensure_grad(bn.weight) if wgrad else None
+        gb = ensure_grad(bn.bias) if bgrad else None
+        if x.g is not None:
+            raise RuntimeError("BN input has more than one consumer; unsupported")
+        x.new_grad() if x.parent is None else _alloc_parent_grad(x)
+        _lib.check(L.gs_bn_bwd_apply(dy.data_ptr(), dy.stride(2), x.ptr, x.ld, out.ptr, out.ld,
+                                     rows, C, coeffs.data_ptr(), bsums.data_ptr(), bcount,
+                                     mask_apply, 1 if use_batch else 0, x.g.data_ptr(),
+                                     x.g.stride(2), gw.data_ptr() if wgrad else None,
+                                     gb.data_ptr() if bgrad else None, s), "gs_bn_bwd_apply")
+        if wgrad:
+            _notify(bn.weight)
+        if bgrad:
+            _notify(bn.bias)
+        if residual is not None and residual.requires_grad:
+            src = dy  # masked (relu) or plain (no relu) upstream gradient
+            if residual.g is None and residual.parent is None and src.stride() == residual.t.stride():
+                residual.g = src
+            else:
+                if residual.g is None:
+                    residual.new_grad() if residual.parent is None else _alloc_parent_grad(residual)
+                    acc = 0 if residual.parent is None else 1
+                else:
+                    acc = 1
+                _lib.check(L.gs_copy2d(src.data_ptr(), src.stride(2), residual.g.data_ptr(),
+                                       residual.g.stride(2), rows, C, 1.0, acc, s), "gs_copy2d")
+
+    tape.record(backward)
+    return out
+
+
+def maxpool(tape, x, k=3, s=2, p=1):
+    L = _L()
+    dev = x.t.device
+    ho, wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
+    out = Act.empty(x.N, ho, wo, x.C, dev)
+    idx = torch.empty((x.N, ho, wo, x.C), dtype=torch.uint8, device=dev)
+    _lib.check(L.gs_maxpool_forward(x.ptr, x.N, x.H, x.W, x.C, x.ld, k, s, p, ho, wo, out.ptr,
+                                    out.ld, idx.data_ptr(), current_stream_ptr()),
+               "gs_maxpool_forward")
+
+    def backward():
+        dy = out.g
+        if dy is None or not x.requires_grad:
+            return
+        acc = x.g is not None
+        if not acc:
+            x.new_grad() if x.parent is None else _alloc_parent_grad(x)
+        _lib.check(L.gs_maxpool_backward(dy.data_ptr(), dy.stride(2), idx.data_ptr(), x.N, x.H, x.W,
+                                         x.C, k, s, p, ho, wo, x.g.data_ptr(), x.g.stride(2),
+                                         1 if acc else 0, current_stream_ptr()),
+                   "gs_maxpool_backward")
+
+    tape.record(backward)
+    return out
+
+
+def copy_into(tape, x, dst):
+    """dst[..., :x.C] = x  (first member of a fused concat)."""
+    L = _L()
+    _lib.check(L.gs_copy2d(x.ptr, x.ld, dst.ptr, dst.ld, x.rows, x.C, 1.0, 0, current_stream_ptr()),
+               "gs_copy2d")
+
+    def backward():
+        dg = dst.g
+        if dg is None or not x.requires_grad:
+            return
+        acc = x.g is not None
+        if not acc:
+            x.new_grad() if x.parent is None else _alloc_parent_grad(x)
+        _lib.check(L.gs_copy2d(dg.data_ptr(), dg.stride(2), x.g.data_ptr(), x.g.stride(2), x.rows,
+                               x.C, 1.0, 1 if acc else 0, current_stream_ptr()), "gs_copy2d")
+
+    tape.record(backward)
+    return dst
+
+
+def adaptive_avgpool(tape, x, scales):
+    """All PPM pool scales in one read of x. Returns one Act [N,s,s,C] per scale."""
+    L = _L()
+    dev = x.t.device
+    ns = len(scales)
+    arr = (ctypes.c_int32 * ns)(*scales)
+    total_bins = sum(s * s for s in scales)
+    ybuf = torch.empty(x.N * total_bins * x.C, dtype=torch.float32, device=dev)
+    nb = L.gs_adaptive_avgpool_workspace_bytes(x.N, x.H, x.W, x.C, arr, ns)
+    ws = _ws.get(nb, dev)
+    _lib.check(L.gs_adaptive_avgpool_forward(x.ptr, x.N, x.H, x.W, x.C, x.ld, arr, ns,
+                                             ybuf.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             current_stream_ptr()), "gs_adaptive_avgpool_forward")
+    outs, off = [], 0
+    for s in scales:
+        n_el = x.N * s * s * x.C
+        outs.append(Act(ybuf[off:off + n_el].view(x.N, s, s, x.C)))
+        off += n_el
+
+    def backward():
+        if not x.requires_grad:
+            return
+        if all(o.g is None for o in outs):
+            return
+        gbuf = torch.zeros_like(ybuf)
+        off2 = 0
+        for s, o in zip(scales, outs):
+            n_el = x.N * s * s * x.C
+            if o.g is not None:
+                gbuf[off2:off2 + n_el].view(x.N, s, s, x.C).copy_(o.g)
+            off2 += n_el
+        acc = x.g is not None
+        if not acc:
+            x.new_grad() if x.parent is None else _alloc_parent_grad(x)
+        _lib.check(L.gs_adaptive_avgpool_backward(gbuf.data_ptr(), x.N, x.H, x.W, x.C, arr, ns,
+                                                  x.g.data_ptr(), x.g.stride(2), 1 if acc else 0,
+                                                  current_stream_ptr()),
+                   "gs_adaptive_avgpool_backward")
+
+    tape.record(backward)
+    return outs
+
+
+def bilinear(tape, x, size, align_corners=False, out=None, accumulate=False):
+    """mmseg.ops.resize(mode='bilinear').  ``out`` may be a channel slice of a concat buffer;
+    ``accumulate`` adds into ``out`` (UPer top-down path)."""
+    L = _L()
+    dev = x.t.device
+    ho, wo = int(size[0]), int(size[1])
+    if out is None:
+        out = Act.empty(x.N, ho, wo, x.C, dev)
+    al = 1 if align_corners else 0
+    _lib.check(L.gs_bilinear_forward(x.ptr, x.N, x.H, x.W, x.C, x.ld, ho, wo, al, out.ptr, out.ld,
+                                     1 if accumulate else 0, current_stream_ptr()),
+               "gs_bilinear_forward")
+
+    def backward():
+        dy = out.g
+        if dy is None or not x.requires_grad:
+            return
+        acc = x.g is not None
+        if not acc:
+            x.new_grad() if x.parent is None else _alloc_parent_grad(x)
+        nb = L.gs_bilinear_backward_workspace_bytes(x.N, x.H, x.W, x.C, ho, wo)
+        ws = _ws.get(nb, dev)
+        _lib.check(L.gs_bilinear_backward(dy.data_ptr(), dy.stride(2), x.N, x.H, x.W, x.C, ho, wo,
+                                          al, x.g.data_ptr(), x.g.stride(2), 1 if acc else 0,
+                                          ws.data_ptr(), ws.numel(), current_stream_ptr()),
+                   "gs_bilinear_backward")
+
+    tape.record(backward)
+    return out
+
+
+def dropout2d(tape, x, p, training, generator=None):
+    """nn.Dropout2d: one Bernoulli(1-p) draw per (n, channel), scaled by 1/(1-p)."""
+    if not training or p <= 0.0:
+        return x
+    L = _L()
+    dev = x.t.device
+    keep = 1.0 - p
+    mask = torch.empty((x.N, x.C), dtype=torch.float32, device=dev)
+    mask.bernoulli_(keep, generator=generator).div_(keep)
+    out = Act.empty(x.N, x.H, x.W, x.C, dev)
+    ppi = x.H * x.W
+    _lib.check(L.gs_scale_nc(x.ptr, x.ld, mask.data_ptr(), x.N, ppi, x.C, out.ptr, out.ld,
+                             current_stream_ptr()), "gs_scale_nc")
+
+    def backward():
+        dy = out.g
+        if dy is None or not x.requires_grad:
+            return
+        if x.g is not None:
+            raise RuntimeError("dropout input has more than one consumer; unsupported")
+        x.new_grad() if x.parent is None else _alloc_parent_grad(x)
+        _lib.check(L.gs_scale_nc(dy.data_ptr(), dy.stride(2), mask.data_ptr(), x.N, ppi, x.C,
+                                 x.g.data_ptr(), x.g.stride(2), current_stream_ptr()),
+                   "gs_scale_nc")
+
+    tape.record(backward)
+    return out
+
+
+def add_grad_passthrough(tape, src, dst):
+    """Record that ``dst`` is the same values as ``src`` (identity edge): route dst.g into src.g."""
+    L = _L()
+
+    def backward():
+        dg = dst.g
+        if dg is None or not src.requires_grad:
+            return
+        if src.g is None and src.parent is None and dg.stride() == src.t.stride():
+            src.g = dg
+            return
+        acc = src.g is not None
+        if not acc:
+            src.new_grad() if src.parent is None else _alloc_parent_grad(src)
+            acc = src.parent is not None
+        _lib.check(L.gs_copy2d(dg.data_ptr(), dg.stride(2), src.g.data_ptr(), src.g.stride(2),
+                               src.rows, src.C, 1.0, 1 if acc else 0, current_stream_ptr()),
+                   "gs_copy2d")
+
+    tape.record(backward)

@@ -1,0 +1,265 @@
+"""Execution runtime of the MI355X path: NHWC activations, a hand-run backward tape, workspaces.
+
+Design (MI355X-first, not a translation of the reference's per-op autograd graph):
+
+* Activations live in HBM as NHWC fp32 (`Act`), possibly as a channel slice of a wider buffer so
+  that ``torch.cat`` never materialises (PPM / FCN / FPN concat fusion).
+* A module-level forward records closures on a `Tape`; the whole backward of a backbone or head is
+  ONE autograd node (`tape_function`) that replays the tape in reverse and writes parameter
+  gradients straight into ``param.grad`` (views of the flat gradient arena when one is installed).
+  Torch autograd only stitches the 4-5 coarse nodes of a step together.
+* Every kernel is launched on torch's current HIP stream through the C-ABI; nothing here computes
+  on the CPU and nothing falls back to eager PyTorch.
+"""
+import torch
+
+from . import lib as _lib
+
+
+def current_stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu_tensor(t, what):
+    if not t.is_cuda:
+        raise _lib.HipLibraryError(
+            "%s is on %s: the gaia_seg_amd operators run only as HIP kernels on an MI355X "
+            "(there is no CPU fallback)" % (what, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (what, t.dtype))
+
+
+class _Workspace:
+    """Grow-only scratch buffer per device (split-K slabs, reduction partials).
+
+    All kernels of a step run in order on one stream, so a single shared buffer is safe."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 256)
+        key = (device.type, device.index)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            # round up generously so later, larger requests rarely reallocate
+            size = max(nbytes, 1 << 20)
+            size = 1 << (size - 1).bit_length()
+            buf = torch.empty(size, dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+    def reserve(self, nbytes, device):
+        self.get(nbytes, device)
+
+
+WORKSPACE = _Workspace()
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Act:
+    """An NHWC activation: ``t`` has shape [N, H, W, C] with strides (H*W*ld, W*ld, ld, 1).
+
+    ``g`` is its gradient (same shape / layout), filled during the backward replay.
+    ``nchw_image`` marks the network input, which is read in place through NCHW strides."""
+
+    __slots__ = ("t", "_g", "requires_grad", "parent", "c0", "nchw_image")
+
+    def __init__(self, t, requires_grad=True, parent=None, c0=0, nchw_image=False):
+        self.t = t
+        self._g = None
+        self.requires_grad = requires_grad
+        self.parent = parent
+        self.c0 = c0
+        self.nchw_image = nchw_image
+
+    # ---- geometry ----
+    @property
+    def N(self):
+        return self.t.shape[0]
+
+    @property
+    def H(self):
+        return self.t.shape[1]
+
+    @property
+    def W(self):
+        return self.t.shape[2]
+
+    @property
+    def C(self):
+        return self.t.shape[3]
+
+    @property
+    def ld(self):
+        return self.t.stride(2)
+
+    @property
+    def rows(self):
+        return self.t.shape[0] * self.t.shape[1] * self.t.shape[2]
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+    # ---- gradient ----
+    @property
+    def g(self):
+        if self.parent is not None:
+            pg = self.parent.g
+            return None if pg is None else pg[..., self.c0:self.c0 + self.C]
+        return self._g
+
+    @g.setter
+    def g(self, value):
+        if self.parent is not None:
+            raise RuntimeError("gradient of a channel slice is owned by its parent buffer")
+        self._g = value
+
+    def new_grad(self):
+        """Allocate (uninitialised) gradient storage with the layout of ``t``."""
+        if self.parent is not None:
+            raise RuntimeError("allocate the gradient on the parent buffer")
+        n, h, w, c = self.t.shape
+        ld = self.t.stride(2)
+        if ld == c:
+            self._g = torch.empty((n, h, w, c), dtype=self.t.dtype, device=self.t.device)
+        else:
+            # padded pixel stride (e.g. 19 classes in 20 floats): the pad columns must stay zero
+            # because the kernels move whole float4s
+            self._g = torch.zeros((n, h, w, ld), dtype=self.t.dtype, device=self.t.device)[..., :c]
+        return self._g
+
+    def slice(self, c0, c1):
+        """Channel slice [c0, c1) as an Act whose gradient is a view of this one's."""
+        return Act(self.t[..., c0:c1], self.requires_grad, parent=self, c0=c0)
+
+    # ---- boundary conversions (logical NCHW tensors at module boundaries) ----
+    @staticmethod
+    def empty(N, H, W, C, device, ld=None, requires_grad=True):
+        ld = ld or round_up(C, 4)
+        buf = torch.empty((N, H, W, ld), dtype=torch.float32, device=device)
+        return Act(buf if ld == C else buf[..., :C], requires_grad)
+
+    @staticmethod
+    def from_nchw(x, requires_grad=None):
+        """Wrap a logical NCHW tensor. Channels-last storage is used in place (no copy); the
+        3-channel image stays NCHW and is read through strides by the stem kernel."""
+        require_gpu_tensor(x, "input tensor")
+        rg = x.requires_grad if requires_grad is None else requires_grad
+        n, c, h, w = x.shape
+        if c % 4 != 0 and x.stride(3) == 1 and not rg:
+            return Act(x.detach(), False, nchw_image=True)
+        xd = x.detach()
+        nhwc = xd.permute(0, 2, 3, 1)
+        ok = (nhwc.stride(3) == 1 and nhwc.stride(2) % 4 == 0 and nhwc.stride(2) >= c
+              and nhwc.stride(1) == w * nhwc.stride(2) and nhwc.stride(0) == h * nhwc.stride(1)
+              and nhwc.data_ptr() % 16 == 0)
+        if not ok:
+            a = Act.empty(n, h, w, c, x.device)
+            a.t.copy_(nhwc)
+            a.requires_grad = rg
+            return a
+        return Act(nhwc, rg)
+
+    def as_nchw(self):
+        return self.t.permute(0, 3, 1, 2)
+
+    def set_grad_from_nchw(self, grad):
+        """Install an upstream gradient given as a logical NCHW tensor (alias when layouts match)."""
+        gn = grad.permute(0, 2, 3, 1)
+        same = (gn.stride() == self.t.stride() and gn.data_ptr() % 16 == 0
+                and gn.dtype == torch.float32)
+        cur = self.g
+        if cur is None:
+            if self.parent is not None:
+                self.parent.new_grad().zero_()
+                self.g.copy_(gn)
+            elif same:
+                self._g = gn
+            else:
+                self.new_grad().copy_(gn)
+        else:
+            cur.add_(gn)
+
+
+class Tape:
+    """Backward closures in forward order; ``backward`` replays them in reverse."""
+
+    __slots__ = ("ops", "enabled")
+
+    def __init__(self, enabled=True):
+        self.ops = []
+        self.enabled = enabled
+
+    def record(self, fn):
+        if self.enabled:
+            self.ops.append(fn)
+
+    def backward(self):
+        ops = self.ops
+        self.ops = []
+        for fn in reversed(ops):
+            fn()
+
+
+class _TapeFunction(torch.autograd.Function):
+    """One autograd node for a whole module forward (backbone, head).
+
+    ``runner(tape, acts_in) -> list[Act]``.  Parameter gradients are written by the tape straight
+    into ``param.grad``; the ``anchor`` input only makes autograd schedule this node."""
+
+    @staticmethod
+    def forward(ctx, runner, anchor, *inputs):
+        need_tape = torch.is_grad_enabled() and (
+            anchor is not None or any(t.requires_grad for t in inputs))
+        tape = Tape(enabled=need_tape)
+        acts_in = [Act.from_nchw(t) for t in inputs]
+        outs = runner(tape, acts_in)
+        ctx.tape = tape
+        ctx.acts_in = acts_in
+        ctx.outs = outs
+        results = tuple(o.as_nchw() for o in outs)
+        return results
+
+    @staticmethod
+    def backward(ctx, *grads):
+        for o, g in zip(ctx.outs, grads):
+            if g is not None:
+                o.set_grad_from_nchw(g)
+        ctx.tape.backward()
+        in_grads = []
+        for a in ctx.acts_in:
+            if a.requires_grad and a.g is not None:
+                in_grads.append(a.g.permute(0, 3, 1, 2))
+            else:
+                in_grads.append(None)
+        ctx.outs = None
+        ctx.acts_in = None
+        return (None, None) + tuple(in_grads)
+
+
+_ANCHORS = {}
+
+
+def grad_anchor(device):
+    """A scalar that requires grad: lets a node whose tensor inputs need no gradient (the image)
+    still take part in backward so that its parameters receive gradients."""
+    key = (device.type, device.index)
+    a = _ANCHORS.get(key)
+    if a is None:
+        a = torch.zeros((), device=device, requires_grad=True)
+        _ANCHORS[key] = a
+    return a
+
+
+def tape_function(runner, inputs, needs_param_grad):
+    """Run ``runner`` as one autograd node. ``inputs`` are logical NCHW tensors."""
+    inputs = list(inputs)
+    for t in inputs:
+        require_gpu_tensor(t, "input tensor")
+    anchor = grad_anchor(inputs[0].device) if (needs_param_grad and torch.is_grad_enabled()) else None
+    return _TapeFunction.apply(runner, anchor, *inputs)

@@ -1,0 +1,221 @@
+"""DynamicResNet backbone — host-side mirror of gaiaseg/models/backbones/dynamic_resnet.py:25-421.
+
+Same registered name, constructor signature, states, ``manipulate_stem`` / ``manipulate_body``,
+init, freezing and ``train()`` behaviour.  ``forward`` returns logical NCHW feature maps (stored
+channels-last) and runs the whole backbone as ONE autograd node over hand-written HIP kernels.
+"""
+from collections.abc import Sequence
+
+import torch.nn as nn
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from ...core.bricks import (DynamicBatchNorm2d, DynamicBottleneck, DynamicConv2d,
+                            build_conv_layer, build_norm_layer, constant_init, kaiming_init)
+from ...core.dynamic import DynamicMixin
+from ...hip import ops
+from ...hip.runtime import tape_function
+from ..builder import BACKBONES
+from ..utils import DynamicResLayer
+
+
+@BACKBONES.register_module()
+class DynamicResNet(nn.Module, DynamicMixin):
+    search_space = {"stem", "body"}
+
+    def init_state(self, stem=None, body=None, **kwargs):
+        if stem is not None:
+            self.stem_state = stem
+        if body is not None:
+            self.body_state = body
+        for k, v in kwargs.items():
+            setattr(self, "%s_state" % k, v)
+
+    def __init__(self, in_channels, stem_width, body_width, body_depth, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3),
+                 style="pytorch", deep_stem=False, avg_down=False, frozen_stages=-1,
+                 frozen_layers=None, conv_cfg=None, norm_cfg=dict(type="DynSyncBN"),
+                 act_cfg=dict(type="ReLU"), norm_eval=False, dcn=None,
+                 stage_with_dcn=(False, False, False, False), plugins=None, with_cp=False,
+                 zero_init_residual=True, contract_dilation=False):
+        super().__init__()
+        self.stem_width, self.body_width = stem_width, body_width
+        self.num_stages = num_stages
+        assert 1 <= num_stages <= 4
+        self.strides, self.dilations = strides, dilations
+        assert len(strides) == len(dilations) == num_stages
+        self.out_indices = out_indices
+        assert max(out_indices) < num_stages
+        self.style, self.deep_stem, self.avg_down = style, deep_stem, avg_down
+        self.frozen_stages, self.frozen_layers = frozen_stages, frozen_layers
+        self.conv_cfg, self.norm_cfg, self.act_cfg = conv_cfg, norm_cfg, act_cfg
+        self.with_cp, self.norm_eval = with_cp, norm_eval
+        self.dcn, self.stage_with_dcn = dcn, stage_with_dcn
+        self.contract_dilation = contract_dilation
+        if dcn is not None:
+            assert len(stage_with_dcn) == num_stages
+            raise NotImplementedError("dcn is not used by the in-tree configs")
+        if plugins is not None:
+            raise NotImplementedError("plugins are not used by the in-tree configs")
+        self.plugins = plugins
+        self.zero_init_residual = zero_init_residual
+        self.block = DynamicBottleneck  # the reference has no BasicBlock (dynamic_resnet.py:132-133)
+        self.body_depth = body_depth[:num_stages]
+        self.inplanes = stem_width[-1] if deep_stem else stem_width
+        self.init_state(stem={"width": stem_width}, body={"depth": body_depth, "width": body_width})
+        self._make_stem_layer(in_channels, stem_width)
+
+        self.res_layers = []
+        for i, num_blocks in enumerate(self.body_depth):
+            planes = body_width[i]
+            res_layer = self.make_res_layer(
+                block=self.block, inplanes=self.inplanes, planes=planes, depth=num_blocks,
+                stride=strides[i], dilation=dilations[i], style=self.style,
+                avg_down=self.avg_down, with_cp=with_cp, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                dcn=None, contract_dilation=contract_dilation, plugins=None)
+            self.inplanes = planes * self.block.expansion
+            layer_name = "layer%d" % (i + 1)
+            self.add_module(layer_name, res_layer)
+            self.res_layers.append(layer_name)
+
+        self._freeze_stages()
+        self._freeze_layers()
+        self.feat_dim = self.block.expansion * body_width[0] * 2 ** (len(self.body_depth) - 1)
+        self.active_feat_dim = self.feat_dim
+
+    def make_res_layer(self, **kwargs):
+        return DynamicResLayer(**kwargs)
+
+    @property
+    def norm1(self):
+        return getattr(self, self.norm1_name)
+
+    def _make_stem_layer(self, in_channels, stem_width):
+        # dynamic_resnet.py:255-302
+        if self.deep_stem:
+            assert isinstance(stem_width, Sequence)
+            self.stem = nn.Sequential(
+                build_conv_layer(self.conv_cfg, in_channels, stem_width[0], kernel_size=3, stride=2,
+                                 padding=1, bias=False),
+                build_norm_layer(self.norm_cfg, stem_width[0])[1],
+                nn.ReLU(inplace=True),
+                build_conv_layer(self.conv_cfg, stem_width[0], stem_width[1], kernel_size=3,
+                                 stride=1, padding=1, bias=False),
+                build_norm_layer(self.norm_cfg, stem_width[1])[1],
+                nn.ReLU(inplace=True),
+                build_conv_layer(self.conv_cfg, stem_width[1], stem_width[2], kernel_size=3,
+                                 stride=1, padding=1, bias=False),
+                build_norm_layer(self.norm_cfg, stem_width[2])[1],
+                nn.ReLU(inplace=True))
+        else:
+            self.conv1 = build_conv_layer(self.conv_cfg, in_channels, stem_width, kernel_size=7,
+                                          stride=2, padding=3, bias=False)
+            self.norm1_name, norm1 = build_norm_layer(self.norm_cfg, stem_width, postfix=1)
+            self.add_module(self.norm1_name, norm1)
+            self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            if self.deep_stem:
+                self.stem.eval()
+                for param in self.stem.parameters():
+                    param.requires_grad = False
+            else:
+                self.norm1.eval()
+                for m in [self.conv1, self.norm1]:
+                    for param in m.parameters():
+                        param.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, "layer%d" % i)
+            m.eval()
+            for param in m.parameters():
+                param.requires_grad = False
+
+    def _freeze_layers(self):
+        if self.frozen_layers is not None:
+            for i, layer_name in enumerate(self.res_layers):
+                res_layer = getattr(self, layer_name)
+                frozen_layer_num = self.frozen_layers[i]
+                assert frozen_layer_num <= len(res_layer)
+                for j in range(frozen_layer_num):
+                    m = res_layer[j]
+                    m.eval()
+                    for param in m.parameters():
+                        param.requires_grad = False
+
+    def init_weights(self, pretrained=None):
+        # dynamic_resnet.py:336-367
+        if isinstance(pretrained, str):
+            from ...core.checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False)
+        elif pretrained is None:
+            for m in self.modules():
+                if isinstance(m, DynamicConv2d):
+                    kaiming_init(m)
+                elif isinstance(m, (_BatchNorm, nn.GroupNorm)):
+                    constant_init(m, 1)
+            if self.zero_init_residual:
+                for m in self.modules():
+                    if isinstance(m, DynamicBottleneck):
+                        constant_init(m.norm3, 0)
+        else:
+            raise TypeError("pretrained must be a str or None")
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        self._freeze_layers()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, _BatchNorm):
+                    m.eval()
+        return self
+
+    def manipulate_stem(self, arch_meta):
+        # dynamic_resnet.py:381-395
+        self.stem_state = arch_meta
+        if self.deep_stem:
+            sliced = [dict(zip(arch_meta, t)) for t in zip(*arch_meta.values())]
+            self.stem[0].manipulate_arch(sliced[0])
+            self.stem[3].manipulate_arch(sliced[1])
+            self.stem[6].manipulate_arch(sliced[2])
+        else:
+            self.conv1.manipulate_arch(arch_meta)
+
+    def manipulate_body(self, arch_meta):
+        # dict of lists -> list of dicts, dynamic_resnet.py:397-403
+        self.body_state = arch_meta
+        sliced = [dict(zip(arch_meta, t)) for t in zip(*arch_meta.values())]
+        for i, layer_name in enumerate(self.res_layers):
+            getattr(self, layer_name).manipulate_arch(sliced[i])
+
+    # ---- execution ----
+    def forward_act(self, tape, x):
+        if self.deep_stem:
+            mods = list(self.stem)
+            for i in range(0, len(mods), 3):  # conv, norm, relu triples
+                x = mods[i].forward_act(tape, x)
+                x = mods[i + 1].forward_act(tape, x, relu=True)
+        else:
+            x = self.conv1.forward_act(tape, x)
+            x = self.norm1.forward_act(tape, x, relu=True)
+        mp = self.maxpool
+        x = ops.maxpool(tape, x, mp.kernel_size, mp.stride, mp.padding)
+        outs = []
+        for i, layer_name in enumerate(self.res_layers):
+            x = getattr(self, layer_name).forward_act(tape, x)
+            if i in self.out_indices:
+                outs.append(x)
+        return outs
+
+    def forward(self, x):
+        needs = any(p.requires_grad for p in self.parameters())
+        return tuple(tape_function(lambda tape, acts: self.forward_act(tape, acts[0]), [x], needs))
+
+    def active_modules(self):
+        """Modules whose parameters take part in the current subnet (depth-skipped blocks are
+        'unused parameters': no gradient, no optimizer update — SURVEY.md Appendix A13)."""
+        mods = [self.stem] if self.deep_stem else [self.conv1, self.norm1]
+        for layer_name in self.res_layers:
+            mods.extend(getattr(self, layer_name).active_blocks())
+        return mods

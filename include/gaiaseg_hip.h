@@ -1,0 +1,262 @@
+/*
+ * gaiaseg_hip.h — C-ABI of the MI355X (gfx950) kernels behind the GAIA-seg supernet hot path.
+ *
+ * The reference (GAIA-seg) has no FFI: every kernel it runs is reached through torch ops called
+ * from Python nn.Modules.  This header therefore declares one entry point
+ * per torch-op call site on the hot path; each comment cites the
+ * reference call site the entry point replaces.  All functions
+ *   - take raw device pointers, sizes, element strides and a hipStream_t passed as void*,
+ *   - allocate nothing (workspaces are passed in; query sizes with the *_workspace_bytes calls),
+ *   - are re-entrant, keep no global state, never synchronise the device,
+ *   - return 0 on success, a negative GS_E_* code for argument errors and a positive hipError_t
+ *     value when a launch failed.
+ *
+ * Tensor conventions (fp32 everywhere, like the reference: fp16_enabled=False,
+ * gaiaseg/models/decode_heads/dynamic_fcn_head.py:81):
+ *   activations : NHWC, element (n,h,w,c) at n*H*W*ld + (h*W + w)*ld + c, ld >= C ("pixel stride"),
+ *                 ld and C multiples of 4 (the only exceptions are the 3-channel input image, read
+ *                 through explicit strides, and num_classes, which the host pads to 4 with zeros);
+ *   conv weight : physical [KH][KW][Ci_max][Co_ld] (HWIO) — the max-size supernet tensor; the
+ *                 kernels read the leading slice [:, :, :Ci, :Co] in place (DynConv2d semantics,
+ *                 SURVEY.md Appendix A1), so no per-step repacking of the sliced weight exists;
+ *   labels      : int64 [N,H,W], ignore_index (255) allowed.
+ */
+#ifndef GAIASEG_HIP_H
+#define GAIASEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_OK 0
+#define GS_E_BADARG (-1)     /* inconsistent / unsupported descriptor */
+#define GS_E_ALIGN (-2)      /* pointer or stride not aligned as documented */
+#define GS_E_WORKSPACE (-3)  /* workspace too small */
+#define GS_E_NULL (-4)       /* required pointer is NULL */
+
+/* ABI version of this header; bumped on any signature change. */
+int gs_abi_version(void);
+/* Human-readable text for a return code of any function below. */
+const char* gs_error_string(int code);
+/* gfx target the library was compiled for ("gfx950"). */
+const char* gs_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Dynamic (slimmable) convolution as implicit GEMM on fp32 MFMA — K1/K2/K3/K6/K10/K11/K12/K16 */
+/* ------------------------------------------------------------------------------------------ */
+/* Replaces F.conv2d(x, weight[:Co,:Ci], bias[:Co], stride, padding, dilation) of gaiavision
+ * DynConv2d as called from DynamicBottleneck / DynamicConvModule / conv_seg
+ * (gaiaseg/models/utils/dynamic_res_layer.py:84-125, gaiaseg/models/backbones/dynamic_resnet.py:255-302,
+ *  gaiaseg/models/decode_heads/dynamic_fcn_head.py:76-126, dynamic_psp_head.py:53-59,123,140-147,
+ *  dynamic_uper_head.py:40-79) and its autograd backward (dgrad / wgrad). */
+typedef struct gs_conv_desc {
+  int32_t N, H, W;        /* input batch and spatial size                                   */
+  int32_t Ci, Co;         /* ACTIVE channels this step (Co padded to a multiple of 4)       */
+  int32_t Ci_max, Co_ld;  /* weight physical dims: [KH][KW][Ci_max][Co_ld], Co_ld % 4 == 0   */
+  int32_t KH, KW;
+  int32_t stride, pad, dil;
+  int32_t Ho, Wo;         /* floor((H + 2p - d(k-1) - 1)/s) + 1, checked by the library      */
+  int64_t x_sn, x_sh, x_sw, x_sc; /* element strides of x (NHWC: x_sc = 1; image: NCHW)     */
+  int32_t ldy;            /* pixel stride of y / dy (>= Co, % 4 == 0)                        */
+  int32_t ld_add;         /* pixel stride of the optional addend (0 if unused)               */
+} gs_conv_desc;
+
+/* bytes of split-K scratch the three calls below may use for this descriptor (max of the three) */
+size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d);
+
+/* y[n,ho,wo,:Co] = conv(x, w[:, :, :Ci, :Co]) (+ bias[:Co]) (+ addend).  bias/addend may be NULL. */
+int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const float* w, const float* bias,
+                      const float* addend, float* y, void* workspace, size_t workspace_bytes,
+                      void* stream);
+/* dx[n,h,w,:Ci] (= or +=) sum_{taps,co} dy * w.   dx is NHWC with pixel stride x_sw (x_sc == 1).
+ * accumulate != 0 adds to the existing dx (residual / multi-consumer gradients). */
+int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
+                    int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* dw[:, :, :Ci, :Co] = sum_pixels x (gathered) * dy, written into the max-size gradient tensor
+ * (same physical layout as w); the rest of dw is left untouched (zero by the host's contract). */
+int gs_conv2d_wgrad(const gs_conv_desc* d, const float* x, const float* dy, float* dw,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[c] = sum over rows of src[r*ld + c], c < C  (conv_seg bias gradient; also used by tests).
+ * workspace >= gs_colsum_workspace_bytes(rows, C). */
+size_t gs_colsum_workspace_bytes(int64_t rows, int32_t C);
+int gs_colsum(const float* src, int64_t rows, int32_t C, int32_t ld, float* out, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Dynamic BatchNorm (+ residual add, + ReLU) — K4, K8                                         */
+/* ------------------------------------------------------------------------------------------ */
+/* Replaces F.batch_norm on the leading C-slice of max-size parameters (gaiavision DynBN /
+ * DynSyncBN; call sites dynamic_resnet.py:267-300,411,
+ * dynamic_res_layer.py:92, DynamicBottleneck norm1-3, DynamicConvModule norm) fused with the
+ * following nn.ReLU(inplace=True) and the bottleneck's `out += identity`.
+ *
+ * Training forward is three launches:
+ *   gs_bn_stats     : per-channel shifted sums  S1 = sum(x - x[0,c]),  S2 = sum (x - x[0,c])^2
+ *                     reduced in a fixed order (deterministic) into sums[2*C]
+ *   (optional all-reduce of sums[] + count across ranks for SyncBN — done by the host)
+ *   gs_bn_finalize  : mean/var -> coeffs {scale = gamma*invstd, beta, mean, invstd}; updates
+ *                     running_mean/var (momentum, unbiased var)
+ *   gs_bn_apply     : y = relu?((x - mean)*scale + beta (+ residual))
+ */
+size_t gs_bn_stats_workspace_bytes(int64_t rows, int32_t C);
+/* sums: [3*C] floats = {S1[C], S2[C], shift[C]} (shift = x[0,c], the conditioning offset). */
+int gs_bn_stats(const float* x, int64_t rows, int32_t C, int32_t ldx, float* sums,
+                void* workspace, size_t workspace_bytes, void* stream);
+/* count = number of samples per channel that produced sums (N*H*W, or the global count for SyncBN).
+ * coeffs: [4*C] = {scale[C], beta[C], mean[C], invstd[C]}.  running_* may be NULL (no update).
+ * gamma/beta may be NULL (treated as 1/0). */
+int gs_bn_finalize(const float* sums, double count, int32_t C, const float* gamma,
+                   const float* beta, float eps, float momentum, float* running_mean,
+                   float* running_var, float* coeffs, void* stream);
+/* Eval-mode coefficients from running statistics (norm_eval / inference). coeffs as above. */
+int gs_bn_eval_coeffs(const float* running_mean, const float* running_var, int32_t C,
+                      const float* gamma, const float* beta, float eps, float* coeffs,
+                      void* stream);
+/* y = act((x - mean)*scale + beta + residual).  residual may be NULL; relu != 0 applies max(.,0).
+ * x and y may alias (in-place).  */
+int gs_bn_apply(const float* x, int64_t rows, int32_t C, int32_t ldx, const float* coeffs,
+                const float* residual, int32_t ld_res, int32_t relu, float* y, int32_t ldy,
+                void* stream);
+
+/* Backward.  mask_mode: 0 = none; 1 = ReLU directly after this BN (mask recomputed from
+ * (x-mean)*scale+beta > 0); 2 = mask from a saved post-activation tensor `act` (> 0), used for the
+ * bottleneck output relu(out + identity) where `act` is the block output.
+ *   gs_bn_bwd_reduce : sums[2*C] = { sum g , sum g*xhat }, g = dy * mask.  If g_out != NULL the
+ *                      masked gradient g is also written there (may alias dy): it is the gradient
+ *                      of the identity branch.
+ *   gs_bn_bwd_apply  : dx = scale * (g - sum_g/count - xhat * sum_gx/count)   (training stats)
+ *                      or dx = scale * g when use_batch_stats == 0 (eval-mode BN in training).
+ *                      Also writes dgamma[:C] = sum_gx, dbeta[:C] = sum_g when non-NULL. */
+size_t gs_bn_bwd_workspace_bytes(int64_t rows, int32_t C);
+int gs_bn_bwd_reduce(const float* dy, int32_t ld_dy, const float* x, int32_t ldx,
+                     const float* act, int32_t ld_act, int64_t rows, int32_t C,
+                     const float* coeffs, int32_t mask_mode, float* g_out, int32_t ld_g,
+                     float* sums, void* workspace, size_t workspace_bytes, void* stream);
+int gs_bn_bwd_apply(const float* dy, int32_t ld_dy, const float* x, int32_t ldx,
+                    const float* act, int32_t ld_act, int64_t rows, int32_t C,
+                    const float* coeffs, const float* sums, double count, int32_t mask_mode,
+                    int32_t use_batch_stats, float* dx, int32_t ld_dx, float* dgamma,
+                    float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Pooling — K5, K7                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (dynamic_resnet.py:302,413), generic k/s/p.
+ * idx (uint8 tap index of the first maximum in (kh,kw) scan order, as ATen) is saved for bwd. */
+int gs_maxpool_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                       int32_t k, int32_t s, int32_t p, int32_t Ho, int32_t Wo, float* y,
+                       int32_t ldy, uint8_t* idx, void* stream);
+/* dx (= or += when accumulate) gather of dy through idx.  */
+int gs_maxpool_backward(const float* dy, int32_t ld_dy, const uint8_t* idx, int32_t N, int32_t H,
+                        int32_t W, int32_t C, int32_t k, int32_t s, int32_t p, int32_t Ho,
+                        int32_t Wo, float* dx, int32_t ld_dx, int32_t accumulate, void* stream);
+
+/* nn.AdaptiveAvgPool2d(s) for all pool_scales of DynamicPPM in ONE read of x
+ * (dynamic_psp_head.py:48-51).  scales[nscales] (e.g. {1,2,3,6}); y is the concatenation over
+ * scales of [N][s][s][C] blocks (pixel stride C).  Bin edges floor(i*H/s), ceil((i+1)*H/s). */
+size_t gs_adaptive_avgpool_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C,
+                                           const int32_t* scales, int32_t nscales);
+int gs_adaptive_avgpool_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,
+                                int32_t ldx, const int32_t* scales, int32_t nscales, float* y,
+                                void* workspace, size_t workspace_bytes, void* stream);
+/* dx (= or +=) sum over scales of dy_bin / bin_area for every bin containing the pixel. */
+int gs_adaptive_avgpool_backward(const float* dy, int32_t N, int32_t H, int32_t W, int32_t C,
+                                 const int32_t* scales, int32_t nscales, float* dx, int32_t ld_dx,
+                                 int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Bilinear resize (align_corners False/True) — K9, K15, K16, K17                              */
+/* ------------------------------------------------------------------------------------------ */
+/* mmseg.ops.resize == F.interpolate(mode='bilinear') (dynamic_psp_head.py:67-71,
+ * dynamic_uper_head.py:108-112,123-127).  Writes into a channel slice of a wider buffer (ldy) so
+ * that torch.cat never materialises (PPM / FPN concat fusion); accumulate != 0 gives the UPer
+ * top-down `laterals[i-1] += resize(laterals[i])` in one pass. */
+int gs_bilinear_forward(const float* x, int32_t N, int32_t Hi, int32_t Wi, int32_t C, int32_t ldx,
+                        int32_t Ho, int32_t Wo, int32_t align_corners, float* y, int32_t ldy,
+                        int32_t accumulate, void* stream);
+/* Adjoint (deterministic gather form): dx (= or +=) sum_p w_p * dy_p.  Large footprints (small
+ * source maps) are split over destination-row slices into the workspace and summed in order. */
+size_t gs_bilinear_backward_workspace_bytes(int32_t N, int32_t Hi, int32_t Wi, int32_t C,
+                                            int32_t Ho, int32_t Wo);
+int gs_bilinear_backward(const float* dy, int32_t ld_dy, int32_t N, int32_t Hi, int32_t Wi,
+                         int32_t C, int32_t Ho, int32_t Wo, int32_t align_corners, float* dx,
+                         int32_t ld_dx, int32_t accumulate, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Elementwise helpers                                                                         */
+/* ------------------------------------------------------------------------------------------ */
+/* dst[r, :C] (= or +=) src[r, :C] * alpha for strided 2-D views (concat slices, grad accumulation). */
+int gs_copy2d(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int64_t rows,
+              int32_t C, float alpha, int32_t accumulate, void* stream);
+/* nn.Dropout2d (fcn_head.py:248-253): y[n,p,c] = x[n,p,c] * mask[n*C + c]; mask already holds
+ * keep/(1-p).  Same kernel is its own backward.  x, y may alias. */
+int gs_scale_nc(const float* x, int32_t ldx, const float* mask, int32_t N, int64_t pixels_per_image,
+                int32_t C, float* y, int32_t ldy, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Pixel-wise cross entropy with on-the-fly bilinear upsampling — K13, K14                     */
+/* ------------------------------------------------------------------------------------------ */
+/* Replaces resize(seg_logit -> label size) + F.cross_entropy(reduction='none', ignore_index) +
+ * weight_reduce_loss(mean over ALL pixels) + accuracy(top-1)
+ * (gaiaseg/models/decode_heads/dynamic_fcn_head.py:137-159; spec copies
+ *  gaiaseg/models/losses/cross_entropy_loss.py:81-92, utils.py:26-55, accuracy.py:38-49).
+ * logits: [N,h,w,Cls] through element strides (l_sn,l_sh,l_sw,l_sc); labels int64 [N,H,W].
+ * pixel_weight: optional float [N,H,W] (OHEM sampler weights), class_weight optional [Cls].
+ * out[0] = sum_i w_i * ce_i (host divides by N*H*W and multiplies loss_weight),
+ * out[1] = number of pixels whose argmax == label.     (both accumulated in double, fixed order)
+ * The full-resolution logits are never materialised. */
+typedef struct gs_ce_desc {
+  int32_t N, h, w, Cls;      /* logits                                                        */
+  int32_t H, W;              /* label / loss resolution                                       */
+  int64_t l_sn, l_sh, l_sw, l_sc;
+  int32_t ignore_index;
+  int32_t align_corners;
+} gs_ce_desc;
+size_t gs_ce_workspace_bytes(const gs_ce_desc* d);
+/* lse: optional float [N,H,W]; when non-NULL the per-pixel log-sum-exp of the resized logits is
+ * saved there for gs_ce_backward (which requires it). */
+int gs_ce_forward(const gs_ce_desc* d, const float* logits, const int64_t* labels,
+                  const float* pixel_weight, const float* class_weight, float* lse, double* out,
+                  void* workspace, size_t workspace_bytes, void* stream);
+/* dlogits[n,y,x,c] = grad_scale * sum_p bilinear_w(p->(y,x)) * w_p * cw * (softmax_p[c] - [c==label_p])
+ * written densely (pixel stride ld_d, columns Cls..ld_d-1 zeroed).  Deterministic gather form:
+ * one workgroup per low-resolution logit pixel walks its bilinear footprint. */
+int gs_ce_backward(const gs_ce_desc* d, const float* logits, const int64_t* labels,
+                   const float* pixel_weight, const float* class_weight, const float* lse,
+                   float grad_scale, float* dlogits, int32_t ld_d, void* stream);
+/* OHEMPixelSampler support: prob[n,Y,X] = softmax(resized logit)[label]
+ * for valid pixels, 2.0 for ignored ones (so they sort last). */
+int gs_ce_label_prob(const gs_ce_desc* d, const float* logits, const int64_t* labels, float* prob,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Inference epilogue — K17                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* argmax over classes of bilinearly resized logits (softmax is monotone):
+ * seg[n,Y,X] = argmax_c resize(logits)[n,c,Y,X]  (dynamic_distiller.py:461-521 whole_inference +
+ * simple_test).  If probs != NULL also writes softmax probabilities [N,H,W,Cls] (aug_test). */
+int gs_resize_argmax(const gs_ce_desc* d, const float* logits, int64_t* seg, float* probs,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Optimiser — K18                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+/* torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov=False) over flat fp32 arenas
+ * (cfg optimizer: configs/_dynamic_/models/pspnet_ar50to101v2_gsync.py:175).  One call updates
+ * one contiguous element range [0,n) of the arenas; the host merges the parameters used this step
+ * into a few ranges (parameters of depth-skipped blocks are not in any range: no update at all).
+ * momentum_buf starts at zero, so the first use gives buf = g exactly as torch does.
+ *   g = grad*grad_scale + weight_decay*p ; buf = momentum*buf + g ; p -= lr*buf
+ * grad_scale is 1/world_size for the data-parallel mean. n % 4 == 0, pointers 16-byte aligned. */
+int gs_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
+                float momentum, float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAIASEG_HIP_H */

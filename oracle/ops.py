@@ -1,0 +1,151 @@
+"""ORACLE (test infrastructure — never imported by the product path).
+
+Plain-PyTorch CPU restatement of the operators on the GAIA-seg supernet hot path.  Each function
+cites the reference lines it follows.  Operators whose source is NOT in /root/reference
+(gaiavision DynConv2d / DynBN, mmseg resize / OHEM) follow the contract reconstructed from the
+reference call sites in SURVEY.md Appendix A and are therefore PARITY UNPINNED (no reference test,
+golden vector or runnable reference exists for them); `weight_reduce_loss` and `accuracy` ARE
+pinned: tests/golden/ref_loss_utils.npz holds outputs of the reference's own
+gaiaseg/models/losses/utils.py and accuracy.py run in the build container
+(tests/golden/make_ref_loss_fixtures.py).
+"""
+import torch
+import torch.nn.functional as F
+
+
+# ---- gaivision DynConv2d: SURVEY.md Appendix A1; call site dynamic_fcn_head.py:76 -------------
+def dyn_conv2d(x, weight, bias, width, stride=1, padding=0, dilation=1):
+    """F.conv2d(x, weight[:width, :x.size(1)], bias[:width], ...): leading-slice convention
+    (in-tree evidence of the convention: gaiaseg/models/backbones/dynamic_convnext.py:95)."""
+    w = weight[:width, :x.size(1)]
+    b = bias[:width] if bias is not None else None
+    return F.conv2d(x, w, b, stride, padding, dilation, 1)
+
+
+# ---- gaiavision DynBN / DynSyncBN(group_size=1): SURVEY.md Appendix A2 -------------------------
+def dyn_batch_norm(x, running_mean, running_var, weight, bias, training, momentum=0.1, eps=1e-5):
+    """F.batch_norm on the leading x.size(1) channels; running stats updated on the slice."""
+    c = x.size(1)
+    rm = running_mean[:c] if running_mean is not None else None
+    rv = running_var[:c] if running_var is not None else None
+    w = weight[:c] if weight is not None else None
+    b = bias[:c] if bias is not None else None
+    return F.batch_norm(x, rm, rv, w, b, training or rm is None, momentum, eps)
+
+
+# ---- mmseg.ops.resize == F.interpolate: call sites dynamic_fcn_head.py:141-145 -----------------
+def resize(input, size=None, scale_factor=None, mode="nearest", align_corners=None):
+    return F.interpolate(input, size, scale_factor, mode, align_corners)
+
+
+# ---- losses: gaiaseg/models/losses/utils.py:7-55 -----------------------------------------------
+def reduce_loss(loss, reduction):
+    """utils.py:7-23"""
+    if reduction == "none":
+        return loss
+    if reduction == "mean":
+        return loss.mean()
+    if reduction == "sum":
+        return loss.sum()
+    raise ValueError(reduction)
+
+
+def weight_reduce_loss(loss, weight=None, reduction="mean", avg_factor=None):
+    """utils.py:26-55: elementwise weight, then mean over ALL elements unless avg_factor."""
+    if weight is not None:
+        assert weight.dim() == loss.dim()
+        if weight.dim() > 1:
+            assert weight.size(1) == 1 or weight.size(1) == loss.size(1)
+        loss = loss * weight
+    if avg_factor is None:
+        loss = reduce_loss(loss, reduction)
+    else:
+        if reduction == "mean":
+            loss = loss.sum() / avg_factor
+        elif reduction != "none":
+            raise ValueError('avg_factor can not be used with reduction="sum"')
+    return loss
+
+
+def cross_entropy(pred, label, weight=None, class_weight=None, reduction="mean", avg_factor=None,
+                  ignore_index=255):
+    """gaiaseg/models/losses/cross_entropy_loss.py:67-94"""
+    loss = F.cross_entropy(pred, label, weight=class_weight, reduction="none",
+                           ignore_index=ignore_index)
+    if weight is not None:
+        weight = weight.float()
+    return weight_reduce_loss(loss, weight=weight, reduction=reduction, avg_factor=avg_factor)
+
+
+def accuracy(pred, target, topk=1, thresh=None):
+    """gaiaseg/models/losses/accuracy.py:4-49 (top-k, % of target.numel())."""
+    assert isinstance(topk, (int, tuple))
+    if isinstance(topk, int):
+        topk = (topk,)
+        return_single = True
+    else:
+        return_single = False
+    maxk = max(topk)
+    if pred.size(0) == 0:
+        accu = [pred.new_tensor(0.) for _ in range(len(topk))]
+        return accu[0] if return_single else accu
+    assert pred.ndim == target.ndim + 1
+    assert pred.size(0) == target.size(0)
+    assert maxk <= pred.size(1)
+    pred_value, pred_label = pred.topk(maxk, dim=1)
+    pred_label = pred_label.transpose(0, 1)
+    correct = pred_label.eq(target.unsqueeze(0).expand_as(pred_label))
+    if thresh is not None:
+        correct = correct & (pred_value > thresh).t()
+    res = []
+    for k in topk:
+        correct_k = correct[:k].reshape(-1).float().sum(0, keepdim=True)
+        res.append(correct_k.mul_(100.0 / target.numel()))
+    return res[0] if return_single else res
+
+
+def seg_losses(seg_logit, seg_label, loss_weight=1.0, ignore_index=255, align_corners=False,
+               sampler=None, class_weight=None):
+    """The `losses` recipe shared by the heads: dynamic_fcn_head.py:137-159
+    (== dynamic_psp_head.py:149-173 minus the 'resize_logit' entry)."""
+    loss = dict()
+    seg_logit = resize(seg_logit, size=seg_label.shape[2:], mode="bilinear",
+                       align_corners=align_corners)
+    seg_weight = sampler(seg_logit, seg_label) if sampler is not None else None
+    seg_label = seg_label.squeeze(1)
+    loss["loss_seg"] = loss_weight * cross_entropy(seg_logit, seg_label, weight=seg_weight,
+                                                   class_weight=class_weight,
+                                                   ignore_index=ignore_index)
+    loss["acc_seg"] = accuracy(seg_logit, seg_label)
+    return loss
+
+
+# ---- mmseg OHEMPixelSampler: SURVEY.md Appendix A11; call sites dynamic_fcn_head.py:70-71,147-148
+def ohem_pixel_weights(seg_logit, seg_label, thresh=None, min_kept=100000, ignore_index=255):
+    with torch.no_grad():
+        assert seg_logit.shape[2:] == seg_label.shape[2:]
+        assert seg_label.shape[1] == 1
+        seg_label = seg_label.squeeze(1).long()
+        batch_kept = min_kept * seg_label.size(0)
+        valid_mask = seg_label != ignore_index
+        seg_weight = seg_logit.new_zeros(size=seg_label.size())
+        valid_seg_weight = seg_weight[valid_mask]
+        if thresh is not None:
+            seg_prob = F.softmax(seg_logit, dim=1)
+            tmp_seg_label = seg_label.clone().unsqueeze(1)
+            tmp_seg_label[tmp_seg_label == ignore_index] = 0
+            seg_prob = seg_prob.gather(1, tmp_seg_label).squeeze(1)
+            sort_prob, sort_indices = seg_prob[valid_mask].sort()
+            if sort_prob.numel() > 0:
+                min_threshold = sort_prob[min(batch_kept, sort_prob.numel() - 1)]
+            else:
+                min_threshold = 0.0
+            threshold = max(min_threshold, thresh)
+            valid_seg_weight[seg_prob[valid_mask] < threshold] = 1.
+        else:
+            losses = F.cross_entropy(seg_logit, seg_label, reduction="none",
+                                     ignore_index=ignore_index)
+            _, sort_indices = losses[valid_mask].sort(descending=True)
+            valid_seg_weight[sort_indices[:batch_kept]] = 1.
+        seg_weight[valid_mask] = valid_seg_weight
+        return seg_weight

@@ -1,0 +1,328 @@
+"""GPU parity of every HIP operator against plain PyTorch on the CPU (the oracle's primitives),
+forward and backward, through the C-ABI.  fp32 MFMA is an exact fmaf chain, so tolerances only
+cover summation-order differences."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 3e-5
+
+
+def _conv_case(ci_max, co_max, ci, co, k, s, p, d, n, h, w, bias=False, seed=0):
+    from gaia_seg_amd.core.bricks import DynamicConv2d
+    torch.manual_seed(seed)
+    m = DynamicConv2d(ci_max, co_max, k, stride=s, padding=p, dilation=d, bias=bias)
+    torch.nn.init.normal_(m.weight, 0, 0.1)
+    if bias:
+        torch.nn.init.normal_(m.bias, 0, 0.5)
+    m.manipulate_width(co)
+    x = torch.randn(n, ci, h, w)
+    w_ref = m.weight.detach().clone().contiguous().requires_grad_(True)
+    b_ref = m.bias.detach().clone().requires_grad_(True) if bias else None
+    x_ref = x.clone().requires_grad_(ci != 3)
+    y_ref = F.conv2d(x_ref, w_ref[:co, :ci], b_ref[:co] if bias else None, s, p, d)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+
+    m = m.to(DEV)
+    xg = x.to(DEV)
+    if ci != 3:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    xg.requires_grad_(ci != 3)
+    y = m(xg)
+    assert y.shape == y_ref.shape
+    e_y = rel_err(y, y_ref)
+    y.backward(gy.to(DEV))
+    e_w = rel_err(m.weight.grad, w_ref.grad)
+    out = {"y": e_y, "dw": e_w}
+    # gradient outside the active slice must be exactly zero
+    gfull = m.weight.grad.detach().cpu()
+    assert float(gfull[co:].abs().max()) == 0.0 if co < co_max else True
+    assert float(gfull[:, ci:].abs().max()) == 0.0 if ci < ci_max else True
+    if ci != 3:
+        out["dx"] = rel_err(xg.grad, x_ref.grad)
+    if bias:
+        out["db"] = rel_err(m.bias.grad, b_ref.grad)
+    return out
+
+
+CONV_CASES = [
+    # ci_max co_max ci  co  k s p d  n  h   w
+    (80, 80, 64, 48, 1, 1, 0, 1, 2, 16, 16),
+    (80, 80, 48, 48, 3, 1, 1, 1, 2, 13, 17),
+    (64, 64, 64, 64, 3, 2, 1, 1, 2, 16, 16),
+    (32, 32, 32, 32, 3, 1, 2, 2, 1, 12, 12),
+    (64, 320, 64, 256, 1, 2, 0, 1, 2, 15, 15),
+    (3, 64, 3, 32, 7, 2, 3, 1, 2, 32, 40),
+    (3, 32, 3, 24, 3, 2, 1, 1, 2, 17, 19),
+    (24, 48, 24, 48, 3, 1, 1, 1, 1, 9, 9),
+    (512, 128, 512, 128, 3, 1, 1, 1, 2, 8, 8),
+    (160, 160, 128, 80, 3, 1, 1, 1, 1, 10, 10),
+    (96, 96, 96, 96, 1, 1, 0, 1, 1, 7, 7),
+    (320, 640, 192, 320, 1, 1, 0, 1, 1, 6, 6),
+    (16, 64, 16, 64, 1, 1, 0, 1, 2, 128, 256),
+    (128, 128, 128, 128, 3, 2, 1, 1, 2, 9, 11),
+    (64, 64, 64, 64, 3, 1, 4, 4, 1, 20, 20),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_dyn_conv2d_fwd_bwd(hip_lib, case):
+    errs = _conv_case(*case)
+    assert max(errs.values()) < TOL, errs
+
+
+def test_conv_seg_19_classes_with_bias(hip_lib):
+    errs = _conv_case(64, 19, 64, 19, 1, 1, 0, 1, 2, 9, 11, bias=True)
+    assert max(errs.values()) < TOL, errs
+
+
+def _bn_case(c_max, c, n, h, w, relu, residual, training=True, seed=0):
+    from gaia_seg_amd.core.bricks import DynamicBatchNorm2d
+    from gaia_seg_amd.hip import ops
+    from gaia_seg_amd.hip.runtime import Act, Tape
+    torch.manual_seed(seed)
+    bn = DynamicBatchNorm2d(c_max)
+    torch.nn.init.uniform_(bn.weight, 0.5, 1.5)
+    torch.nn.init.normal_(bn.bias, 0, 0.3)
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    bn.train(training)
+    x = torch.randn(n, c, h, w) * 2 + 0.7
+    r = torch.randn(n, c, h, w) if residual else None
+    # --- reference ---
+    ref = torch.nn.BatchNorm2d(c_max)
+    ref.load_state_dict(bn.state_dict())
+    ref.train(training)
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if residual else None
+    wr, br = ref.weight, ref.bias
+    yr = F.batch_norm(xr, ref.running_mean[:c], ref.running_var[:c], wr[:c], br[:c], training,
+                      0.1, 1e-5)
+    if residual:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    # --- HIP ---
+    bn = bn.to(DEV)
+    tape = Tape()
+    xa = Act.from_nchw(x.to(DEV).contiguous(memory_format=torch.channels_last), requires_grad=True)
+    ra = Act.from_nchw(r.to(DEV).contiguous(memory_format=torch.channels_last), requires_grad=True) if residual else None
+    ya = bn.forward_act(tape, xa, relu=relu, residual=ra)
+    errs = {"y": rel_err(ya.as_nchw(), yr)}
+    ya.set_grad_from_nchw(gy.to(DEV).contiguous(memory_format=torch.channels_last).clone())
+    tape.backward()
+    errs["dx"] = rel_err(xa.g.permute(0, 3, 1, 2), xr.grad)
+    errs["dgamma"] = rel_err(bn.weight.grad[:c], wr.grad[:c])
+    errs["dbeta"] = rel_err(bn.bias.grad[:c], br.grad[:c])
+    if residual:
+        errs["dres"] = rel_err(ra.g.permute(0, 3, 1, 2), rr.grad)
+    if training:
+        errs["rm"] = rel_err(bn.running_mean, ref.running_mean)
+        errs["rv"] = rel_err(bn.running_var, ref.running_var)
+    if c < c_max:
+        assert float(bn.weight.grad[c:].abs().max()) == 0.0
+    return errs
+
+
+BN_CASES = [
+    (80, 48, 2, 9, 11, True, False),
+    (64, 64, 2, 16, 16, True, True),
+    (80, 80, 1, 5, 7, False, False),
+    (320, 320, 2, 6, 6, True, True),
+    (640, 640, 2, 4, 4, True, False),
+    (2560, 2048, 2, 3, 3, False, True),
+    (512, 512, 2, 1, 1, True, False),   # PPM scale 1: two samples per channel
+    (512, 512, 2, 6, 6, True, False),
+    (64, 64, 2, 64, 128, True, False),
+]
+
+
+@pytest.mark.parametrize("case", BN_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_dyn_batchnorm_train(hip_lib, case):
+    errs = _bn_case(*case)
+    assert max(errs.values()) < 2e-4, errs
+
+
+def test_dyn_batchnorm_eval_mode(hip_lib):
+    errs = _bn_case(80, 64, 2, 7, 9, True, True, training=False)
+    assert max(errs.values()) < 1e-4, errs
+
+
+def test_bn_near_constant_two_samples(hip_lib):
+    """s=1 PPM branch: variance from two nearly equal samples must not cancel catastrophically."""
+    from gaia_seg_amd.core.bricks import DynamicBatchNorm2d
+    bn = DynamicBatchNorm2d(8).to(DEV)
+    x = torch.tensor([1.0, 1.001]).view(2, 1, 1, 1).repeat(1, 8, 1, 1)
+    y = bn(x.to(DEV).contiguous(memory_format=torch.channels_last))
+    ref = F.batch_norm(x, None, None, None, None, True, 0.1, 1e-5)
+    assert rel_err(y, ref) < 1e-3
+
+
+def _nhwc(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def test_maxpool_fwd_bwd(hip_lib):
+    from gaia_seg_amd.hip import ops
+    from gaia_seg_amd.hip.runtime import Act, Tape
+    torch.manual_seed(0)
+    for (n, c, h, w) in [(2, 32, 17, 19), (1, 64, 32, 64)]:
+        x = torch.relu(torch.randn(n, c, h, w))  # many exact ties at zero
+        xr = x.clone().requires_grad_(True)
+        yr = F.max_pool2d(xr, 3, 2, 1)
+        gy = torch.randn_like(yr)
+        yr.backward(gy)
+        tape = Tape()
+        xa = Act.from_nchw(_nhwc(x), requires_grad=True)
+        ya = ops.maxpool(tape, xa, 3, 2, 1)
+        assert torch.equal(ya.as_nchw().cpu(), yr.detach())
+        ya.set_grad_from_nchw(_nhwc(gy))
+        tape.backward()
+        assert rel_err(xa.g.permute(0, 3, 1, 2), xr.grad) < 1e-6
+
+
+def test_adaptive_avgpool_fwd_bwd(hip_lib):
+    from gaia_seg_amd.hip import ops
+    from gaia_seg_amd.hip.runtime import Act, Tape
+    torch.manual_seed(0)
+    for (n, c, h, w) in [(2, 64, 16, 32), (1, 2048, 7, 9), (2, 32, 64, 128)]:
+        scales = [1, 2, 3, 6]
+        x = torch.randn(n, c, h, w)
+        xr = x.clone().requires_grad_(True)
+        yrs = [F.adaptive_avg_pool2d(xr, s) for s in scales]
+        gys = [torch.randn_like(y) for y in yrs]
+        torch.autograd.backward(yrs, gys)
+        tape = Tape()
+        xa = Act.from_nchw(_nhwc(x), requires_grad=True)
+        yas = ops.adaptive_avgpool(tape, xa, scales)
+        for ya, yr, gy in zip(yas, yrs, gys):
+            assert rel_err(ya.as_nchw(), yr) < 1e-5
+            ya.set_grad_from_nchw(_nhwc(gy))
+        tape.backward()
+        assert rel_err(xa.g.permute(0, 3, 1, 2), xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("align", [False, True])
+def test_bilinear_fwd_bwd(hip_lib, align):
+    from gaia_seg_amd.hip import ops
+    from gaia_seg_amd.hip.runtime import Act, Tape
+    torch.manual_seed(0)
+    cases = [((2, 16, 6, 6), (16, 32)), ((1, 32, 1, 1), (16, 32)), ((2, 8, 25, 25), (49, 49)),
+             ((1, 8, 49, 49), (97, 97)), ((1, 16, 2, 3), (64, 128)), ((1, 8, 16, 16), (8, 8))]
+    for shape, size in cases:
+        x = torch.randn(*shape)
+        xr = x.clone().requires_grad_(True)
+        yr = F.interpolate(xr, size=size, mode="bilinear", align_corners=align)
+        gy = torch.randn_like(yr)
+        yr.backward(gy)
+        tape = Tape()
+        xa = Act.from_nchw(_nhwc(x), requires_grad=True)
+        ya = ops.bilinear(tape, xa, size, align)
+        assert rel_err(ya.as_nchw(), yr) < 1e-5, (shape, size)
+        ya.set_grad_from_nchw(_nhwc(gy))
+        tape.backward()
+        assert rel_err(xa.g.permute(0, 3, 1, 2), xr.grad) < 1e-5, (shape, size)
+
+
+def test_bilinear_accumulate_and_slice(hip_lib):
+    """resize-add (UPer top-down) and writing into a channel slice of a concat buffer."""
+    from gaia_seg_amd.hip import ops
+    from gaia_seg_amd.hip.runtime import Act, Tape
+    torch.manual_seed(0)
+    coarse, fine = torch.randn(2, 16, 5, 7), torch.randn(2, 16, 9, 13)
+    ref = fine + F.interpolate(coarse, size=(9, 13), mode="bilinear", align_corners=False)
+    tape = Tape(enabled=False)
+    fa = Act.from_nchw(_nhwc(fine), requires_grad=False)
+    ops.bilinear(tape, Act.from_nchw(_nhwc(coarse), False), (9, 13), False, out=fa, accumulate=True)
+    assert rel_err(fa.as_nchw(), ref) < 1e-5
+    cat = Act.empty(2, 9, 13, 48, torch.device(DEV))
+    cat.t.zero_()
+    ops.bilinear(tape, Act.from_nchw(_nhwc(coarse), False), (9, 13), False, out=cat.slice(16, 32))
+    up = F.interpolate(coarse, size=(9, 13), mode="bilinear", align_corners=False)
+    assert rel_err(cat.as_nchw()[:, 16:32], up) < 1e-5
+    assert float(cat.t[..., :16].abs().max()) == 0 and float(cat.t[..., 32:].abs().max()) == 0
+
+
+def test_dropout2d_mask_semantics(hip_lib):
+    from gaia_seg_amd.hip import ops
+    from gaia_seg_amd.hip.runtime import Act, Tape
+    torch.manual_seed(0)
+    x = torch.randn(2, 64, 5, 7)
+    tape = Tape()
+    xa = Act.from_nchw(_nhwc(x), requires_grad=True)
+    ya = ops.dropout2d(tape, xa, 0.5, True)
+    y = ya.as_nchw().cpu()
+    ratio = y / x
+    # one Bernoulli draw per (n, channel): the ratio is constant over the spatial dims, 0 or 2
+    per = ratio.flatten(2)
+    assert torch.allclose(per, per[..., :1].expand_as(per), atol=1e-6)
+    vals = per[..., 0].unique()
+    assert set(vals.round().tolist()) <= {0.0, 2.0}
+    ya.set_grad_from_nchw(_nhwc(torch.ones_like(x)))
+    tape.backward()
+    assert torch.allclose(xa.g.permute(0, 3, 1, 2).cpu(), per[..., :1].view(2, 64, 1, 1).expand_as(x))
+
+
+def _ce_ref(logits, label, size, ignore=255, weight=None, cw=None, lw=1.0, align=False):
+    up = F.interpolate(logits, size=size, mode="bilinear", align_corners=align)
+    loss = F.cross_entropy(up, label, weight=cw, reduction="none", ignore_index=ignore)
+    if weight is not None:
+        loss = loss * weight
+    acc = (up.argmax(1) == label).float().sum() * (100.0 / label.numel())
+    return lw * loss.mean(), acc
+
+
+@pytest.mark.parametrize("shape", [((2, 19, 16, 32), (64, 128)), ((2, 19, 5, 7), (33, 41)),
+                                   ((1, 19, 25, 25), (97, 97)), ((2, 150, 4, 4), (16, 16)),
+                                   ((1, 19, 8, 8), (8, 8))])
+def test_fused_resize_ce_fwd_bwd(hip_lib, shape):
+    from gaia_seg_amd.hip.runtime import Act
+    from gaia_seg_amd.models.losses import seg_loss_and_accuracy
+    (n, c, h, w), size = shape
+    torch.manual_seed(0)
+    logits = torch.randn(n, c, h, w) * 3
+    label = torch.randint(0, c, (n, *size))
+    label[:, :3, :] = 255
+    label[0, 5:9, 2:7] = 255
+    pw = (torch.rand(n, *size) > 0.3).float()
+    for weight, cw in [(None, None), (pw, torch.rand(c) + 0.5)]:
+        lr = logits.clone().requires_grad_(True)
+        loss_r, acc_r = _ce_ref(lr, label, size, weight=weight, cw=cw, lw=0.4)
+        loss_r.backward()
+        a = Act.empty(n, h, w, c, torch.device(DEV))
+        a.t.copy_(logits.permute(0, 2, 3, 1))
+        lg = a.as_nchw().requires_grad_(True)
+        loss, acc = seg_loss_and_accuracy(lg, label.to(DEV),
+                                          weight.to(DEV) if weight is not None else None,
+                                          cw.to(DEV) if cw is not None else None, 255, False, 0.4)
+        assert abs(float(loss) - float(loss_r)) < 2e-5 * max(1.0, abs(float(loss_r)))
+        assert abs(float(acc) - float(acc_r)) < 1e-3
+        (loss * 2.5).backward()
+        assert rel_err(lg.grad, lr.grad * 2.5) < 5e-5
+
+
+def test_sgd_step_matches_torch(hip_lib):
+    import ctypes
+    from gaia_seg_amd.hip import lib
+    from gaia_seg_amd.hip.runtime import current_stream_ptr
+    torch.manual_seed(0)
+    n = 4096 + 8
+    p = torch.randn(n)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    pg, buf = p.to(DEV), torch.zeros(n, device=DEV)
+    for step in range(3):
+        g = torch.randn(n)
+        pr.grad = g.clone()
+        opt.step()
+        gg = g.to(DEV)
+        lib.check(hip_lib.gs_sgd_step(pg.data_ptr(), gg.data_ptr(), buf.data_ptr(), n, 0.01, 0.9,
+                                      5e-4, 1.0, current_stream_ptr()), "sgd")
+    assert rel_err(pg, pr) < 1e-6
