@@ -195,11 +195,13 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     for (int si = 0; si < sc.n; ++si) {
       const int s = sc.s[si];
       const float* base = dy + (long)N * sc.off[si] * C + (long)n * s * s * C + cq * 4;
-      const int ic = (h * s) / H, jc = (w * s) / W;
-      for (int bi = max(ic - 1, 0); bi <= min(ic + 1, s - 1); ++bi) {
+      // bins that can contain h: floor(h*s/H)-1 .. ceil((h+1)*s/H)  (several when s > H)
+      const int ilo = max((h * s) / H - 1, 0), ihi = min(((h + 1) * s + H - 1) / H, s - 1);
+      const int jlo = max((w * s) / W - 1, 0), jhi = min(((w + 1) * s + W - 1) / W, s - 1);
+      for (int bi = ilo; bi <= ihi; ++bi) {
         const int h0 = bin_lo(bi, H, s), h1 = bin_hi(bi, H, s);
         if (h < h0 || h >= h1) continue;
-        for (int bj = max(jc - 1, 0); bj <= min(jc + 1, s - 1); ++bj) {
+        for (int bj = jlo; bj <= jhi; ++bj) {
           const int w0 = bin_lo(bj, W, s), w1 = bin_hi(bj, W, s);
           if (w < w0 || w >= w1) continue;
           const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));

@@ -213,9 +213,8 @@ class _TapeFunction(torch.autograd.Function):
     into ``param.grad``; the ``anchor`` input only makes autograd schedule this node."""
 
     @staticmethod
-    def forward(ctx, runner, anchor, *inputs):
-        need_tape = torch.is_grad_enabled() and (
-            anchor is not None or any(t.requires_grad for t in inputs))
+    def forward(ctx, runner, need_tape, anchor, *inputs):
+        # (grad mode is always off inside Function.forward: the caller decides need_tape)
         tape = Tape(enabled=need_tape)
         acts_in = [Act.from_nchw(t) for t in inputs]
         outs = runner(tape, acts_in)
@@ -239,7 +238,7 @@ class _TapeFunction(torch.autograd.Function):
                 in_grads.append(None)
         ctx.outs = None
         ctx.acts_in = None
-        return (None, None) + tuple(in_grads)
+        return (None, None, None) + tuple(in_grads)
 
 
 _ANCHORS = {}
@@ -261,5 +260,7 @@ def tape_function(runner, inputs, needs_param_grad):
     inputs = list(inputs)
     for t in inputs:
         require_gpu_tensor(t, "input tensor")
-    anchor = grad_anchor(inputs[0].device) if (needs_param_grad and torch.is_grad_enabled()) else None
-    return _TapeFunction.apply(runner, anchor, *inputs)
+    grad_on = torch.is_grad_enabled()
+    anchor = grad_anchor(inputs[0].device) if (needs_param_grad and grad_on) else None
+    need_tape = grad_on and (anchor is not None or any(t.requires_grad for t in inputs))
+    return _TapeFunction.apply(runner, need_tape, anchor, *inputs)

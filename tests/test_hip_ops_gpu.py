@@ -192,7 +192,7 @@ def test_adaptive_avgpool_fwd_bwd(hip_lib):
     from gaia_seg_amd.hip import ops
     from gaia_seg_amd.hip.runtime import Act, Tape
     torch.manual_seed(0)
-    for (n, c, h, w) in [(2, 64, 16, 32), (1, 2048, 7, 9), (2, 32, 64, 128)]:
+    for (n, c, h, w) in [(2, 64, 16, 32), (1, 2048, 7, 9), (2, 32, 64, 128), (2, 16, 2, 3), (1, 8, 4, 4)]:
         scales = [1, 2, 3, 6]
         x = torch.randn(n, c, h, w)
         xr = x.clone().requires_grad_(True)
