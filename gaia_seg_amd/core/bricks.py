@@ -157,12 +157,12 @@ class DynamicConv2d(nn.Module, DynamicMixin):
         return out
 
     # ---- execution ----
-    def forward_act(self, tape, x, out=None):
+    def forward_act(self, tape, x, out=None, tag=None):
         self._check_layout()
         if getattr(self, "_deploying", False):
             self._deploy_slice(x.C)
         return ops.conv2d(tape, x, self.weight, self.bias, self.width_state, self.stride,
-                          self.padding, self.dilation, out=out)
+                          self.padding, self.dilation, out=out, tag=tag)
 
     def forward(self, x):
         needs = any(p.requires_grad for p in self.parameters())
@@ -253,7 +253,23 @@ class DynamicBatchNorm2d(_BatchNorm, DynamicMixin):
         return ops.BNParams(self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                             self.momentum, training,
                             process_group=self._process_group() if training else None,
-                            num_batches_tracked=self.num_batches_tracked)
+                            num_batches_tracked=self._count_batch
+                            if self.num_batches_tracked is not None else None)
+
+    def _count_batch(self):
+        """num_batches_tracked += 1 without a device op per BN per step: counted on the host and
+        folded into the buffer whenever it is read through state_dict()."""
+        self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
+
+    def flush_counters(self):
+        pending = getattr(self, "_nbt_pending", 0)
+        if pending and self.num_batches_tracked is not None:
+            self.num_batches_tracked += pending
+        self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_counters()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
 
     def forward_act(self, tape, x, relu=False, residual=None, out=None):
         if getattr(self, "_deploying", False):
@@ -447,7 +463,7 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
     def forward_act(self, tape, x):
         out = self.conv1.forward_act(tape, x)
         out = self.norm1.forward_act(tape, out, relu=True)
-        out = self.conv2.forward_act(tape, out)
+        out = self.conv2.forward_act(tape, out, tag="k3")  # the roofline kernel
         out = self.norm2.forward_act(tape, out, relu=True)
         out = self.conv3.forward_act(tape, out)
         identity = x

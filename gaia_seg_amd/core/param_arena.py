@@ -1,0 +1,108 @@
+"""Flat fp32 arenas for parameters, gradients and SGD momentum (laid out for 288 GB of HBM3E).
+
+Every parameter of the supernet becomes a view into ONE contiguous buffer (and its gradient a view
+into a second one with identical offsets), in forward order.  This gives
+  * a fused SGD step over a few merged ranges instead of ~300 small tensors (K18: torch.optim.SGD of
+    configs/_dynamic_/models/pspnet_ar50to101v2_gsync.py:175 — momentum 0.9, weight decay 5e-4),
+  * zero-copy gradient buckets for the data-parallel all-reduce (the reducer all-reduces slices of
+    the flat gradient buffer; nothing is packed or unpacked),
+  * one memset to clear the gradients of a step.
+Only the parameters that take part in the sampled subnet are touched by a step: depth-skipped
+blocks get no gradient and no update at all (DECIDE); inactive width
+slices of used tensors have zero gradient but do receive weight decay / momentum, like the
+reference (they belong to a tensor that has a gradient).
+"""
+import torch
+
+from ..hip import lib as _lib
+from ..hip.runtime import current_stream_ptr, round_up
+from .bricks import hwio_logical_view
+
+_ALIGN = 64  # floats: 256-byte aligned segments (float4 loads need 16 B; keep cache lines whole)
+
+
+class ParamArena:
+    def __init__(self, model):
+        params = [(n, p) for n, p in model.named_parameters()]
+        if not params:
+            raise ValueError("model has no parameters")
+        dev = params[0][1].device
+        if dev.type != "cuda":
+            raise _lib.HipLibraryError("ParamArena needs the model on the MI355X (got %s)" % dev)
+        self.device = dev
+        self.segments = {}   # id(param) -> (offset, numel_phys)
+        self.names = {}
+        off = 0
+        layout = []
+        for name, p in params:
+            phys = getattr(p, "_gs_phys_shape", None)
+            n_phys = 1
+            for s in (phys if phys is not None else p.shape):
+                n_phys *= s
+            layout.append((name, p, phys, off, n_phys))
+            off += round_up(max(n_phys, 1), _ALIGN)
+        self.numel = off
+        self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_mom = torch.zeros(off, dtype=torch.float32, device=dev)
+        for name, p, phys, o, n in layout:
+            pv = self._view(self.flat_param, p, phys, o, n)
+            pv.copy_(p.data)
+            p.data = pv
+            p.grad = self._view(self.flat_grad, p, phys, o, n)
+            # gradients now always exist: drop the lazy factories
+            if hasattr(p, "_gs_grad_factory"):
+                del p._gs_grad_factory
+            self.segments[id(p)] = (o, round_up(max(n, 1), _ALIGN))
+            self.names[id(p)] = name
+        self._range_cache = {}
+
+    @staticmethod
+    def _view(flat, p, phys, off, n):
+        seg = flat[off:off + n]
+        if phys is None:
+            return seg.view(p.shape)
+        if len(phys) == 4:   # conv weight, physical HWIO
+            return hwio_logical_view(seg.view(*phys), p.shape[0])
+        if len(phys) == 1:   # padded conv bias
+            return seg[:p.shape[0]]
+        raise ValueError("unknown physical layout %s" % (phys,))
+
+    # ---- ranges ----
+    def ranges_for(self, params, key=None):
+        """Merged [begin, end) element ranges covering ``params`` (cached by ``key``)."""
+        if key is not None and key in self._range_cache:
+            return self._range_cache[key]
+        segs = sorted(self.segments[id(p)] for p in params)
+        merged = []
+        for o, n in segs:
+            if merged and merged[-1][1] == o:
+                merged[-1][1] = o + n
+            else:
+                merged.append([o, o + n])
+        merged = [tuple(r) for r in merged]
+        if key is not None:
+            self._range_cache[key] = merged
+        return merged
+
+    def zero_grad(self, ranges=None):
+        if ranges is None:
+            self.flat_grad.zero_()
+        else:
+            for a, b in ranges:
+                self.flat_grad[a:b].zero_()
+
+    def sgd_step(self, ranges, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
+        """torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov=False) on the ranges."""
+        L = _lib.load()
+        st = current_stream_ptr()
+        pb, gb, mb = self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.flat_mom.data_ptr()
+        for a, b in ranges:
+            _lib.check(L.gs_sgd_step(pb + 4 * a, gb + 4 * a, mb + 4 * a, b - a, lr, momentum,
+                                     weight_decay, grad_scale, st), "gs_sgd_step")
+
+    def state_dict(self):
+        return {"momentum": self.flat_mom}
+
+    def load_state_dict(self, sd):
+        self.flat_mom.copy_(sd["momentum"])

@@ -17,6 +17,7 @@
 // A and B tiles are staged global -> registers -> LDS (issue-early / write-late double buffer, one
 // barrier per K step); LDS images are k-major with a per-4-row skew so that both the transposed
 // stores and the MFMA fragment reads (lane l reads [k = l>>4][i = l&15]) are bank-conflict free.
+#pragma once
 #include <algorithm>
 #include "common.h"
 
@@ -120,7 +121,8 @@ __device__ __forceinline__ void acc_to_lds(float* __restrict__ Cs,
 // ------------------------------------------------------------------------------------------
 // forward / dgrad: GEMM rows are pixels, the gathered operand is A.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, bool BTRANS, bool DIVS, bool SCALAR>
+// KS: compile-time kernel size (1 or 3; 0 = runtime KW) — also tags the kernel name in profiles
+template <int BM, int BN, bool BTRANS, bool DIVS, bool SCALAR, int KS>
 __global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
   __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
 
   auto gather = [&](int s, int tap, int c) -> const float* {
     // returns the address of src element for row slot s / (tap, c), or nullptr when padded
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int kwid = KS ? KS : p.KW;
+    const int kh = KS == 1 ? 0 : tap / kwid, kw = KS == 1 ? 0 : tap - kh * kwid;
     const int hn = hb[s] + kh * p.step_h, wn = wb[s] + kw * p.step_w;
     int hi = hn, wi = wn;
     bool ok = rv[s] && tap < p.taps;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
 // ------------------------------------------------------------------------------------------
 // wgrad: GEMM rows are (tap, ci), K runs over pixels; both operands are k-major in memory.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, bool SCALAR>
+template <int BM, int BN, bool SCALAR, int KS>
 __global__ __launch_bounds__(NT) void igemm_wgrad_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
   __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
@@ -340,7 +343,8 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_kernel(const IgemmArgs p) {
     iv[e] = i < p.M;
     const int ii = iv[e] ? i : 0;
     const int tap = ii / p.Cs, c = ii - tap * p.Cs;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int kwid = KS ? KS : p.KW;
+    const int kh = tap / kwid, kw = tap - kh * kwid;
     offh[e] = p.base_h + kh * p.step_h;
     offw[e] = p.base_w + kw * p.step_w;
     offc[e] = (long)c * p.s_c;
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_kernel(const IgemmArgs p) {
 
 // Fixed-order sum of the split-K partial slabs + epilogue.  rows_are_taps selects the wgrad
 // output addressing.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, int splits,
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, int splits,
                                                             int rows_are_taps) {
   const int qpr = p.Nn / 4;
   const long total = (long)p.M * qpr;
@@ -521,12 +525,12 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split) {
   return pl;
 }
 
-template <bool BTRANS, bool DIVS, bool SCALAR>
+template <bool BTRANS, bool DIVS, bool SCALAR, int KS>
 static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
   const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
 #define GS_ROWS(BM_, BN_)                                                                     \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                         \
-    hipLaunchKernelGGL((igemm_rows_kernel<BM_, BN_, BTRANS, DIVS, SCALAR>), grid, block, 0, st, a); \
+    hipLaunchKernelGGL((igemm_rows_kernel<BM_, BN_, BTRANS, DIVS, SCALAR, KS>), grid, block, 0, st, a); \
     return;                                                                                   \
   }
   GS_ROWS(128, 128) GS_ROWS(128, 96) GS_ROWS(128, 80) GS_ROWS(128, 64) GS_ROWS(128, 48) GS_ROWS(128, 32)
@@ -534,12 +538,12 @@ static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
 #undef GS_ROWS
 }
 
-template <bool SCALAR>
+template <bool SCALAR, int KS>
 static void launch_wgrad(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
   const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
 #define GS_WG(BM_, BN_)                                                                \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                  \
-    hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, SCALAR>), grid, block, 0, st, a); \
+    hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, SCALAR, KS>), grid, block, 0, st, a); \
     return;                                                                            \
   }
   GS_WG(128, 128) GS_WG(128, 96) GS_WG(128, 80) GS_WG(128, 64) GS_WG(128, 48) GS_WG(128, 32)
@@ -578,149 +582,16 @@ static size_t slab_bytes(const Plan& pl, long M, int Nn) {
   return pl.splits > 1 ? (size_t)pl.splits * M * Nn * sizeof(float) : 0;
 }
 
-static void launch_reduce(const IgemmArgs& a, int splits, int rows_are_taps, hipStream_t st) {
+static inline void launch_reduce(const IgemmArgs& a, int splits, int rows_are_taps, hipStream_t st) {
   const long total = (long)a.M * (a.Nn / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, a,
                      splits, rows_are_taps);
 }
 
+static inline int ksize_tag(const gs_conv_desc* d) {
+  if (d->KH == 1 && d->KW == 1) return 1;
+  if (d->KH == 3 && d->KW == 3) return 3;
+  return 0;
+}
+
 }  // namespace gs
-
-using namespace gs;
-
-extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
-  if (check_desc(d) != GS_OK) return 0;
-  size_t b = 0;
-  {
-    const Plan pl = plan_fwd(d);
-    b = std::max(b, slab_bytes(pl, (long)d->N * d->Ho * d->Wo, d->Co));
-  }
-  if (d->x_sc == 1 && (d->Ci & 3) == 0) {
-    const Plan pl = plan_dgrad(d);
-    b = std::max(b, slab_bytes(pl, (long)d->N * d->H * d->W, d->Ci));
-  }
-  {
-    const Plan pl = plan_wgrad(d);
-    b = std::max(b, slab_bytes(pl, (long)d->KH * d->KW * d->Ci, d->Co));
-  }
-  return b;
-}
-
-extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const float* w,
-                                 const float* bias, const float* addend, float* y, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
-  int rc = check_desc(d);
-  if (rc != GS_OK) return rc;
-  if (!x || !w || !y) return GS_E_NULL;
-  if (!aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) || (addend && !aligned16(addend)))
-    return GS_E_ALIGN;
-  if (addend && ((d->ld_add & 3) || d->ld_add < d->Co)) return GS_E_ALIGN;
-  const bool vec = x_is_vector(d);
-  if (vec && !aligned16(x)) return GS_E_ALIGN;
-  const Plan pl = plan_fwd(d);
-  const long M = (long)d->N * d->Ho * d->Wo;
-  const size_t need = slab_bytes(pl, M, d->Co);
-  if (need > workspace_bytes || (need && !workspace)) return GS_E_WORKSPACE;
-
-  IgemmArgs a{};
-  a.src = x; a.dense = w; a.out = y; a.slab = need ? static_cast<float*>(workspace) : nullptr;
-  a.bias = bias; a.addend = addend;
-  a.s_n = d->x_sn; a.s_h = d->x_sh; a.s_w = d->x_sw; a.s_c = d->x_sc;
-  a.Hs = d->H; a.Ws = d->W; a.Cs = d->Ci;
-  a.Hp = d->Ho; a.Wp = d->Wo; a.npix = (int)M;
-  a.KW = d->KW; a.taps = d->KH * d->KW;
-  a.mul_h = a.mul_w = d->stride; a.base_h = a.base_w = -d->pad;
-  a.step_h = a.step_w = d->dil; a.div_h = a.div_w = 1;
-  a.d_tap = (long)d->Ci_max * d->Co_ld; a.d_row = d->Co_ld; a.n_lim = d->Co;
-  a.M = (int)M; a.Nn = d->Co; a.Ktot = a.taps * d->Ci;
-  a.ld_out = d->ldy; a.ld_add = d->ld_add;
-  a.nk_total = pl.nk_total; a.nk_per_split = pl.nk_per_split;
-  a.accumulate = 0; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
-  hipStream_t st = as_stream(stream);
-  if (vec) launch_rows<false, false, false>(pl, a, st);
-  else launch_rows<false, false, true>(pl, a, st);
-  rc = launch_status();
-  if (rc != GS_OK) return rc;
-  if (pl.splits > 1) {
-    launch_reduce(a, pl.splits, 0, st);
-    rc = launch_status();
-  }
-  return rc;
-}
-
-extern "C" int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
-                               int accumulate, void* workspace, size_t workspace_bytes,
-                               void* stream) {
-  int rc = check_desc(d);
-  if (rc != GS_OK) return rc;
-  if (!dy || !w || !dx) return GS_E_NULL;
-  if (d->x_sc != 1 || (d->Ci & 3) || (d->x_sw & 3)) return GS_E_ALIGN;
-  if (d->x_sh != (int64_t)d->W * d->x_sw || d->x_sn != (int64_t)d->H * d->x_sh) return GS_E_BADARG;
-  if (!aligned16(dy) || !aligned16(w) || !aligned16(dx)) return GS_E_ALIGN;
-  const Plan pl = plan_dgrad(d);
-  const long M = (long)d->N * d->H * d->W;
-  const size_t need = slab_bytes(pl, M, d->Ci);
-  if (need > workspace_bytes || (need && !workspace)) return GS_E_WORKSPACE;
-
-  IgemmArgs a{};
-  a.src = dy; a.dense = w; a.out = dx; a.slab = need ? static_cast<float*>(workspace) : nullptr;
-  a.s_c = 1; a.s_w = d->ldy; a.s_h = (long)d->Wo * d->ldy; a.s_n = (long)d->Ho * a.s_h;
-  a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;
-  a.Hp = d->H; a.Wp = d->W; a.npix = (int)M;
-  a.KW = d->KW; a.taps = d->KH * d->KW;
-  a.mul_h = a.mul_w = 1; a.base_h = a.base_w = d->pad;
-  a.step_h = a.step_w = -d->dil; a.div_h = a.div_w = d->stride;
-  a.d_tap = (long)d->Ci_max * d->Co_ld; a.d_row = d->Co_ld; a.n_lim = d->Ci;
-  a.M = (int)M; a.Nn = d->Ci; a.Ktot = a.taps * d->Co;
-  a.ld_out = (int)d->x_sw; a.ld_add = 0;
-  a.nk_total = pl.nk_total; a.nk_per_split = pl.nk_per_split;
-  a.accumulate = accumulate ? 1 : 0; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
-  hipStream_t st = as_stream(stream);
-  if (d->stride == 1) launch_rows<true, false, false>(pl, a, st);
-  else launch_rows<true, true, false>(pl, a, st);
-  rc = launch_status();
-  if (rc != GS_OK) return rc;
-  if (pl.splits > 1) {
-    launch_reduce(a, pl.splits, 0, st);
-    rc = launch_status();
-  }
-  return rc;
-}
-
-extern "C" int gs_conv2d_wgrad(const gs_conv_desc* d, const float* x, const float* dy, float* dw,
-                               void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = check_desc(d);
-  if (rc != GS_OK) return rc;
-  if (!x || !dy || !dw) return GS_E_NULL;
-  if (!aligned16(dy) || !aligned16(dw)) return GS_E_ALIGN;
-  const bool vec = x_is_vector(d);
-  if (vec && !aligned16(x)) return GS_E_ALIGN;
-  const Plan pl = plan_wgrad(d);
-  const long M = (long)d->KH * d->KW * d->Ci;
-  const size_t need = slab_bytes(pl, M, d->Co);
-  if (need > workspace_bytes || (need && !workspace)) return GS_E_WORKSPACE;
-
-  IgemmArgs a{};
-  a.src = x; a.dense = dy; a.out = dw; a.slab = need ? static_cast<float*>(workspace) : nullptr;
-  a.s_n = d->x_sn; a.s_h = d->x_sh; a.s_w = d->x_sw; a.s_c = d->x_sc;
-  a.Hs = d->H; a.Ws = d->W; a.Cs = d->Ci;
-  a.Hp = d->Ho; a.Wp = d->Wo; a.npix = d->N * d->Ho * d->Wo;
-  a.KW = d->KW; a.taps = d->KH * d->KW;
-  a.mul_h = a.mul_w = d->stride; a.base_h = a.base_w = -d->pad;
-  a.step_h = a.step_w = d->dil; a.div_h = a.div_w = 1;
-  a.d_tap = 0; a.d_row = d->ldy; a.n_lim = d->Co;
-  a.M = (int)M; a.Nn = d->Co; a.Ktot = a.npix;
-  a.o_tap = (long)d->Ci_max * d->Co_ld; a.o_row = d->Co_ld;
-  a.nk_total = pl.nk_total; a.nk_per_split = pl.nk_per_split;
-  a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
-  hipStream_t st = as_stream(stream);
-  if (vec) launch_wgrad<false>(pl, a, st);
-  else launch_wgrad<true>(pl, a, st);
-  rc = launch_status();
-  if (rc != GS_OK) return rc;
-  if (pl.splits > 1) {
-    launch_reduce(a, pl.splits, 1, st);
-    rc = launch_status();
-  }
-  return rc;
-}

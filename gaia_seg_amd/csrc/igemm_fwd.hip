@@ -1,0 +1,68 @@
+// DynConv2d forward (implicit GEMM, fp32 MFMA) — see igemm_core.h
+#include "igemm_core.h"
+
+using namespace gs;
+
+extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
+  if (check_desc(d) != GS_OK) return 0;
+  size_t b = 0;
+  {
+    const Plan pl = plan_fwd(d);
+    b = std::max(b, slab_bytes(pl, (long)d->N * d->Ho * d->Wo, d->Co));
+  }
+  if (d->x_sc == 1 && (d->Ci & 3) == 0) {
+    const Plan pl = plan_dgrad(d);
+    b = std::max(b, slab_bytes(pl, (long)d->N * d->H * d->W, d->Ci));
+  }
+  {
+    const Plan pl = plan_wgrad(d);
+    b = std::max(b, slab_bytes(pl, (long)d->KH * d->KW * d->Ci, d->Co));
+  }
+  return b;
+}
+
+extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const float* w,
+                                 const float* bias, const float* addend, float* y, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc != GS_OK) return rc;
+  if (!x || !w || !y) return GS_E_NULL;
+  if (!aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) || (addend && !aligned16(addend)))
+    return GS_E_ALIGN;
+  if (addend && ((d->ld_add & 3) || d->ld_add < d->Co)) return GS_E_ALIGN;
+  const bool vec = x_is_vector(d);
+  if (vec && !aligned16(x)) return GS_E_ALIGN;
+  const Plan pl = plan_fwd(d);
+  const long M = (long)d->N * d->Ho * d->Wo;
+  const size_t need = slab_bytes(pl, M, d->Co);
+  if (need > workspace_bytes || (need && !workspace)) return GS_E_WORKSPACE;
+
+  IgemmArgs a{};
+  a.src = x; a.dense = w; a.out = y; a.slab = need ? static_cast<float*>(workspace) : nullptr;
+  a.bias = bias; a.addend = addend;
+  a.s_n = d->x_sn; a.s_h = d->x_sh; a.s_w = d->x_sw; a.s_c = d->x_sc;
+  a.Hs = d->H; a.Ws = d->W; a.Cs = d->Ci;
+  a.Hp = d->Ho; a.Wp = d->Wo; a.npix = (int)M;
+  a.KW = d->KW; a.taps = d->KH * d->KW;
+  a.mul_h = a.mul_w = d->stride; a.base_h = a.base_w = -d->pad;
+  a.step_h = a.step_w = d->dil; a.div_h = a.div_w = 1;
+  a.d_tap = (long)d->Ci_max * d->Co_ld; a.d_row = d->Co_ld; a.n_lim = d->Co;
+  a.M = (int)M; a.Nn = d->Co; a.Ktot = a.taps * d->Ci;
+  a.ld_out = d->ldy; a.ld_add = d->ld_add;
+  a.nk_total = pl.nk_total; a.nk_per_split = pl.nk_per_split;
+  a.accumulate = 0; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
+  hipStream_t st = as_stream(stream);
+  const int ks = ksize_tag(d);
+  if (!vec) launch_rows<false, false, true, 0>(pl, a, st);
+  else if (ks == 1) launch_rows<false, false, false, 1>(pl, a, st);
+  else if (ks == 3) launch_rows<false, false, false, 3>(pl, a, st);
+  else launch_rows<false, false, false, 0>(pl, a, st);
+  rc = launch_status();
+  if (rc != GS_OK) return rc;
+  if (pl.splits > 1) {
+    launch_reduce(a, pl.splits, 0, st);
+    rc = launch_status();
+  }
+  return rc;
+}
+

@@ -104,12 +104,20 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const CeArgs a, const float
   }
 }
 
-__global__ void ce_final_kernel(const double* __restrict__ part, int nparts, double* out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double l = 0.0, c = 0.0;
-    for (int p = 0; p < nparts; ++p) { l += part[2 * p]; c += part[2 * p + 1]; }
-    out[0] = l;
-    out[1] = c;
+// one block: lanes stride over the partials, fixed-order wave + LDS combine (bit-reproducible)
+__global__ __launch_bounds__(256) void ce_final_kernel(const double* __restrict__ part, int nparts,
+                                                       double* out) {
+  __shared__ double sh[8];
+  double l = 0.0, c = 0.0;
+  for (int p = threadIdx.x; p < nparts; p += 256) { l += part[2 * p]; c += part[2 * p + 1]; }
+  l = wave_sum_d(l);
+  c = wave_sum_d(c);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sh[wave] = l; sh[4 + wave] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = sh[0] + sh[1] + sh[2] + sh[3];
+    out[1] = sh[4] + sh[5] + sh[6] + sh[7];
   }
 }
 
@@ -253,7 +261,7 @@ extern "C" int gs_ce_forward(const gs_ce_desc* d, const float* logits, const int
   double* part = static_cast<double*>(workspace);
   hipLaunchKernelGGL(ce_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, a, logits, labels,
                      pixel_weight, class_weight, lse, part, (float*)nullptr);
-  hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(64), 0, st, part, grid, out);
+  hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(256), 0, st, part, grid, out);
   return launch_status();
 }
 

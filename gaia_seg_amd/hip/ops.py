@@ -69,7 +69,36 @@ def _conv_desc(x, weight, co, stride, pad, dil, ldy, ld_add=0):
     return d
 
 
-def conv2d(tape, x, weight, bias, co, stride=1, pad=0, dil=1, out=None):
+class KernelTimer:
+    """Optional HIP-event timing of tagged kernel launches on the current stream (bench.py uses it
+    to time the dynamic 3x3 bottleneck conv inside real training steps)."""
+
+    def __init__(self):
+        self.records = {}   # tag -> list of (start_event, end_event, flops)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, tag, start, flops):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.setdefault(tag, []).append((start, e, flops))
+
+    def summary(self):
+        """tag -> (launches, total_ms, total_flops); call after a device synchronize."""
+        out = {}
+        for tag, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            out[tag] = (len(recs), ms, float(sum(f for _, _, f in recs)))
+        return out
+
+
+TIMER = None  # set to a KernelTimer to enable
+
+
+def conv2d(tape, x, weight, bias, co, stride=1, pad=0, dil=1, out=None, tag=None):
     """DynConv2d forward: y = conv(x, weight[:co, :x.C]) (+ bias[:co]).
 
     ``co`` is the active output width; the active input width is x.C."""
@@ -88,9 +117,15 @@ def conv2d(tape, x, weight, bias, co, stride=1, pad=0, dil=1, out=None):
     need = L.gs_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _ws.get(need, dev)
     st = current_stream_ptr()
+    timed = TIMER is not None and tag is not None
+    if timed:
+        t0 = TIMER.begin()
     _lib.check(L.gs_conv2d_forward(ctypes.byref(d), x.ptr, weight.data_ptr(),
                                    bias.data_ptr() if bias is not None else None, None, out.ptr,
                                    ws.data_ptr(), ws.numel(), st), "gs_conv2d_forward")
+    if timed:
+        ci = x.t.shape[1] if x.nchw_image else x.C
+        TIMER.end(tag + ".fwd", t0, 2.0 * n * ho * wo * co * ci * kh * kw)
 
     def backward():
         dy = out.g
@@ -203,7 +238,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
         _lib.check(L.gs_bn_finalize(sums.data_ptr(), count, C, gamma, beta, bn.eps, mom, rm, rv,
                                     coeffs.data_ptr(), st), "gs_bn_finalize")
         if bn.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+            bn.num_batches_tracked()  # host-side counter: no device op per BN per step
     else:
         _lib.check(L.gs_bn_eval_coeffs(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), C,
                                        gamma, beta, bn.eps, coeffs.data_ptr(), st),

@@ -45,7 +45,7 @@ def _run_pair(cfg, arch, deep_stem=False, size=(64, 96), check_grads=True):
             n_checked += 1
         assert n_checked > 10
         ob = dict(orc.named_buffers())
-        for name, b in prod.named_buffers():
+        for name, b in prod.state_dict().items():  # state_dict() folds the host-side BN counters
             if name.endswith("running_mean") or name.endswith("running_var"):
                 errs["buf:" + name] = rel_err(b, ob[name])
             elif name.endswith("num_batches_tracked"):
