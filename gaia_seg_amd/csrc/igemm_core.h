@@ -50,6 +50,7 @@ struct IgemmArgs {
   int nk_total, nk_per_split;
   int accumulate;
   int tiles_m, tiles_n;
+  unsigned src_bytes, dense_bytes;  // extents for the bounds-checked buffer loads (0 = unknown)
 };
 
 // k-major LDS image with skew: element (k, i) at k*P + 8*(k>>2) + i, P % 32 == 16.
@@ -313,6 +314,200 @@ __global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
   }
 }
 
+// Shared epilogue of the row kernels: accumulators -> LDS -> coalesced float4 rows.
+template <int BM, int BN>
+__device__ __forceinline__ void rows_epilogue(
+    const IgemmArgs& p, float* lds, const f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN], int m0,
+    int n0, int t, int wave, int lane) {
+  using T = Tile<BM, BN>;
+  float* Cs = lds;
+  constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch > 0) __syncthreads();
+    acc_to_lds<BM, BN>(Cs, acc, ch, wave, lane);
+    __syncthreads();
+    constexpr int QPR = T::CCH / 4;
+    for (int idx = t; idx < BM * QPR; idx += NT) {
+      const int row = idx / QPR, q = idx - row * QPR;
+      const int m = m0 + row;
+      const int col = n0 + ch * T::CCH + q * 4;
+      if (ch * T::CCH + q * 4 < BN && m < p.M && col < p.Nn) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * T::PC + q * 4]);
+        if (p.slab) {
+          *reinterpret_cast<f32x4*>(p.slab + ((long)blockIdx.y * p.M + m) * p.Nn + col) = v;
+        } else {
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+          if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (long)m * p.ld_add + col);
+          float* o = p.out + (long)m * p.ld_out + col;
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+          *reinterpret_cast<f32x4*>(o) = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fast path of forward / stride-1 dgrad for the shapes that carry the FLOPs: NHWC source,
+// channels per tap a multiple of BK (every width of the search space is a multiple of 16), 1x1 or
+// 3x3.  Versus the general kernel above:
+//  * a K step never straddles a tap, so (tap, channel) is block-uniform: scalar registers;
+//  * the per-row gather is hoisted out of the K loop: one base pointer and one tap-validity
+//    bit mask per row slot, so a K step costs a mask test and one add per load (the general
+//    kernel spent ~100 VALU + ~60 SALU instructions per K step on index math, r01 ISA census);
+//  * global loads run TWO K steps ahead of the MFMAs (two register sets), because one K step of
+//    fp32 MFMA work (~1k cycles per wave) is shorter than the gather's memory latency.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, bool BTRANS, int KS>
+__global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) {
+  using T = Tile<BM, BN>;
+  __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
+  constexpr int AS = BM / 64;
+  constexpr int TAPS = KS * KS;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kt0 = blockIdx.y * p.nk_per_split;
+  const int kt1 = min(kt0 + p.nk_per_split, p.nk_total);
+  const int nk = kt1 - kt0;
+
+  // ---- per-thread constants of the gather ----
+  const int kq = t & 3;
+  // bounds-checked buffer loads: an offset >= num_records returns 0, so padding / ragged edges
+  // need no branch (the K loop stays one basic block the compiler can software-pipeline)
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dense =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dense), 0, p.dense_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0xFFFFFFFFu;
+  int rowoff[AS];  // byte offset of (n, hb, wb, kq*4); wraps for the (masked) negative halo
+  unsigned vmask[AS];
+  const int hw = p.Hp * p.Wp;
+#pragma unroll
+  for (int s = 0; s < AS; ++s) {
+    const int m = m0 + (t >> 2) + 64 * s;
+    const bool rv = m < p.M;
+    const int mm = rv ? m : 0;
+    const int n = mm / hw;
+    const int rem = mm - n * hw;
+    const int hp = rem / p.Wp;
+    const int wp = rem - hp * p.Wp;
+    const int hb = hp * p.mul_h + p.base_h, wb = wp * p.mul_w + p.base_w;
+    rowoff[s] = (int)(4 * ((long)n * p.s_n + (long)hb * p.s_h + (long)wb * p.s_w + kq * 4));
+    unsigned mk = 0;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+      const int hi = hb + (tp / KS) * p.step_h, wi = wb + (tp % KS) * p.step_w;
+      const bool ok = rv && (unsigned)hi < (unsigned)p.Hs && (unsigned)wi < (unsigned)p.Ws;
+      mk |= (ok ? 1u : 0u) << tp;
+    }
+    vmask[s] = mk;
+  }
+  // ---- per-thread constants of the dense operand ----
+  int boff[T::BV];  // bytes
+  bool bok[T::BV];
+#pragma unroll
+  for (int r = 0; r < T::BV; ++r) {
+    const int idx = t + NT * r;
+    const bool iv = idx < BK * BN / 4;
+    if constexpr (!BTRANS) {
+      const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
+      const int col = n0 + nq * 4;
+      bok[r] = iv && col < p.n_lim;
+      boff[r] = 4 * (kr * p.d_row + col);
+    } else {
+      const int nrow = idx >> 2, kq2 = idx & 3;
+      const int ng = n0 + nrow;
+      bok[r] = iv && ng < p.Nn;
+      boff[r] = 4 * (ng * p.d_row + kq2 * 4);
+    }
+  }
+
+  // block-uniform position of the next K step to load
+  int tap = (kt0 * BK) / p.Cs;
+  int c0 = kt0 * BK - tap * p.Cs;
+
+  f32x4 acc[T::TM][T::TN];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load = [&](f32x4 (&ra)[AS], f32x4 (&rb)[T::BV]) {
+    const bool kvalid = tap < TAPS;
+    const int kh = tap / KS, kw = tap - kh * KS;
+    const int aoff = 4 * (kh * p.step_h * (int)p.s_h + kw * p.step_w * (int)p.s_w + c0);
+#pragma unroll
+    for (int s = 0; s < AS; ++s) {
+      const bool ok = kvalid && ((vmask[s] >> tap) & 1u);
+      const unsigned off = ok ? (unsigned)(rowoff[s] + aoff) : kOOB;
+      ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
+    }
+    const int bbase = 4 * (tap * (int)p.d_tap + (BTRANS ? c0 : c0 * p.d_row));
+#pragma unroll
+    for (int r = 0; r < T::BV; ++r) {
+      const unsigned off = (bok[r] && kvalid) ? (unsigned)(boff[r] + bbase) : kOOB;
+      rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dense, off, 0, 0));
+    }
+    c0 += BK;
+    if (c0 >= p.Cs) { c0 = 0; ++tap; }
+  };
+
+  auto store = [&](const f32x4 (&ra)[AS], const f32x4 (&rb)[T::BV], int buf) {
+    float* As = lds + buf * T::STAGE;
+    float* Bs = As + T::A_SZ;
+#pragma unroll
+    for (int s = 0; s < AS; ++s) {
+      const int row = (t >> 2) + 64 * s;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * T::PA + 8 * kq + row] = ra[s][j];
+    }
+#pragma unroll
+    for (int r = 0; r < T::BV; ++r) {
+      const int idx = t + NT * r;
+      if (idx < BK * BN / 4) {
+        if constexpr (!BTRANS) {
+          const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
+          *reinterpret_cast<f32x4*>(&Bs[kr * T::PB + 8 * (kr >> 2) + nq * 4]) = rb[r];
+        } else {
+          const int nrow = idx >> 2, kq2 = idx & 3;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Bs[(kq2 * 4 + j) * T::PB + 8 * kq2 + nrow] = rb[r][j];
+        }
+      }
+    }
+  };
+
+  f32x4 ra0[AS], ra1[AS];
+  f32x4 rb0[T::BV], rb1[T::BV];
+  float* buf0 = lds;
+  float* buf1 = lds + T::STAGE;
+  if (nk > 0) {
+    load(ra0, rb0);
+    if (nk > 1) load(ra1, rb1);
+    store(ra0, rb0, 0);
+    __syncthreads();
+    for (int i = 0; i < nk; i += 2) {
+      // even phase: MFMAs on step i (buf0); set 1 holds step i+1 (in flight); refill set 0 with i+2
+      if (i + 2 < nk) load(ra0, rb0);
+      mfma_stage<BM, BN>(buf0, buf0 + T::A_SZ, acc, wave, lane);
+      if (i + 1 < nk) store(ra1, rb1, 1);
+      __syncthreads();
+      if (i + 1 >= nk) break;
+      // odd phase: MFMAs on step i+1 (buf1); set 0 holds step i+2; refill set 1 with i+3
+      if (i + 3 < nk) load(ra1, rb1);
+      mfma_stage<BM, BN>(buf1, buf1 + T::A_SZ, acc, wave, lane);
+      if (i + 2 < nk) store(ra0, rb0, 0);
+      __syncthreads();
+    }
+  }
+  rows_epilogue<BM, BN>(p, lds, acc, m0, n0, t, wave, lane);
+}
+
 // ------------------------------------------------------------------------------------------
 // wgrad: GEMM rows are (tap, ci), K runs over pixels; both operands are k-major in memory.
 // ------------------------------------------------------------------------------------------
@@ -494,6 +689,15 @@ struct Plan {
 static const int kBN[6] = {128, 96, 80, 64, 48, 32};
 constexpr size_t kMaxSlabBytes = 96u << 20;
 
+// Tuning knobs (read once): GS_WG_TARGET = workgroups a launch should reach before we stop
+// shrinking tiles / splitting K (default 2 per CU); GS_MIN_KSTEPS = K steps per split at least.
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+static int wg_target() { static const int v = env_int("GS_WG_TARGET", 2 * kNumCU); return v; }
+static int min_ksteps() { static const int v = env_int("GS_MIN_KSTEPS", 4); return v; }
+
 static Plan make_plan(int M, int Nn, int Ktot, bool allow_split) {
   Plan pl{};
   // BN: least padded width, larger tile on ties
@@ -508,13 +712,13 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split) {
   pl.nk_total = (int)ceil_div(Ktot, BK);
   // BM: 128 when that still fills the chip, else 64
   const long t128 = ceil_div(M, 128) * pl.tiles_n;
-  pl.bm = (t128 >= 2 * kNumCU) ? 128 : 64;
+  pl.bm = (t128 >= wg_target()) ? 128 : 64;
   pl.tiles_m = (int)ceil_div(M, pl.bm);
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   int splits = 1;
-  if (allow_split && tiles < 2 * kNumCU && pl.nk_total >= 8) {
-    splits = (int)ceil_div(2 * kNumCU, tiles);
-    const int max_by_k = pl.nk_total / 4;  // at least 4 K steps per split
+  if (allow_split && tiles < wg_target() && pl.nk_total >= 2 * min_ksteps()) {
+    splits = (int)ceil_div(wg_target(), tiles);
+    const int max_by_k = pl.nk_total / min_ksteps();
     if (splits > max_by_k) splits = max_by_k;
     if (splits > 64) splits = 64;
     while (splits > 1 && (size_t)splits * M * Nn * sizeof(float) > kMaxSlabBytes) --splits;
@@ -536,6 +740,25 @@ static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
   GS_ROWS(128, 128) GS_ROWS(128, 96) GS_ROWS(128, 80) GS_ROWS(128, 64) GS_ROWS(128, 48) GS_ROWS(128, 32)
   GS_ROWS(64, 128) GS_ROWS(64, 96) GS_ROWS(64, 80) GS_ROWS(64, 64) GS_ROWS(64, 48) GS_ROWS(64, 32)
 #undef GS_ROWS
+}
+
+template <bool BTRANS, int KS>
+static void launch_rows_fast(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
+  const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
+#define GS_FAST(BM_, BN_)                                                                  \
+  if (pl.bm == BM_ && pl.bn == BN_) {                                                      \
+    hipLaunchKernelGGL((igemm_rows_fast_kernel<BM_, BN_, BTRANS, KS>), grid, block, 0, st, a); \
+    return;                                                                                \
+  }
+  GS_FAST(128, 128) GS_FAST(128, 96) GS_FAST(128, 80) GS_FAST(128, 64) GS_FAST(128, 48) GS_FAST(128, 32)
+  GS_FAST(64, 128) GS_FAST(64, 96) GS_FAST(64, 80) GS_FAST(64, 64) GS_FAST(64, 48) GS_FAST(64, 32)
+#undef GS_FAST
+}
+
+// the fast row kernel needs: NHWC vector source, channels per tap % BK == 0, 1x1 or 3x3
+static inline bool fast_rows_ok(int cs, int ks, size_t src_bytes, size_t dense_bytes) {
+  return (ks == 1 || ks == 3) && (cs % BK) == 0 && src_bytes < (1ull << 31) &&
+         dense_bytes < (1ull << 31);
 }
 
 template <bool SCALAR, int KS>

@@ -32,8 +32,15 @@ extern "C" int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const flo
   a.accumulate = accumulate ? 1 : 0; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
   hipStream_t st = as_stream(stream);
   const int ks = ksize_tag(d);
+  const size_t src_b = (size_t)d->N * a.s_n * sizeof(float);
+  const size_t dense_b = (size_t)a.taps * a.d_tap * sizeof(float);
+  a.src_bytes = (unsigned)src_b;
+  a.dense_bytes = (unsigned)dense_b;
+  const bool fast = fast_rows_ok(d->Co, ks, src_b, dense_b) && getenv("GS_NO_FAST") == nullptr;
   if (d->stride == 1) {
-    if (ks == 1) launch_rows<true, false, false, 1>(pl, a, st);
+    if (fast && ks == 1) launch_rows_fast<true, 1>(pl, a, st);
+    else if (fast && ks == 3) launch_rows_fast<true, 3>(pl, a, st);
+    else if (ks == 1) launch_rows<true, false, false, 1>(pl, a, st);
     else if (ks == 3) launch_rows<true, false, false, 3>(pl, a, st);
     else launch_rows<true, false, false, 0>(pl, a, st);
   } else {

@@ -53,7 +53,14 @@ extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const fl
   a.accumulate = 0; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
   hipStream_t st = as_stream(stream);
   const int ks = ksize_tag(d);
+  const size_t src_b = (size_t)d->N * d->x_sn * sizeof(float);
+  const size_t dense_b = (size_t)a.taps * a.d_tap * sizeof(float);
+  a.src_bytes = (unsigned)src_b;
+  a.dense_bytes = (unsigned)dense_b;
+  const bool fast = vec && fast_rows_ok(d->Ci, ks, src_b, dense_b) && getenv("GS_NO_FAST") == nullptr;
   if (!vec) launch_rows<false, false, true, 0>(pl, a, st);
+  else if (fast && ks == 1) launch_rows_fast<false, 1>(pl, a, st);
+  else if (fast && ks == 3) launch_rows_fast<false, 3>(pl, a, st);
   else if (ks == 1) launch_rows<false, false, false, 1>(pl, a, st);
   else if (ks == 3) launch_rows<false, false, false, 3>(pl, a, st);
   else launch_rows<false, false, false, 0>(pl, a, st);
