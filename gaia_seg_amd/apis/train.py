@@ -1,0 +1,101 @@
+"""train_segmentor — host-side mirror of gaiaseg/apis/train.py:47-186.
+
+Same call contract (model, train_sampler, val_sampler, dataset, cfg, distributed, validate,
+timestamp, meta) and the same feature switches read with cfg.get (manipulate_arch :142,
+lr_scaler :103-113, resume_from / load_from :172-175).  What differs by design:
+  * the model is not wrapped in MMDistributedDataParallel: parameters and gradients live in flat
+    arenas and a bucketed RCCL all-reduce over slices of the gradient arena is driven by the
+    backward tape (core/dist.py);
+  * the optimizer is the fused flat-arena SGD kernel (cfg.optimizer must be SGD, as in the
+    in-tree config);
+  * datasets: the reference's CityscapesDataset19 is not defined anywhere and
+    no dataset exists offline, so ``type='SyntheticSegDataset'`` (seeded tensors of the pipeline's
+    output shapes) is the built-in loader; any iterable of
+    dict(img, img_metas, gt_semantic_seg) batches is accepted.
+"""
+import random
+
+import numpy as np
+import torch
+
+from ..core import dist as gdist
+from ..core.param_arena import ParamArena
+from ..core.runner import (ArenaOptimizerHook, CheckpointHook, FixedLrUpdaterHook,
+                           IterBasedRunner, ManipulateArchHook, PolyLrUpdaterHook, TextLoggerHook)
+from ..core.synthetic import SyntheticLoader
+
+
+def set_random_seed(seed, deterministic=False):
+    """gaiaseg/apis/train.py:30-45.  (The HIP kernels are bit-reproducible regardless of
+    ``deterministic``: no float atomics are used anywhere on the path.)"""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def build_dataloader(dataset_cfg, samples_per_gpu, seed=0, device="cuda", num_classes=19):
+    if isinstance(dataset_cfg, (list, tuple)):
+        dataset_cfg = dataset_cfg[0]
+    if isinstance(dataset_cfg, dict):
+        t = dataset_cfg.get("type")
+        if t != "SyntheticSegDataset":
+            raise NotImplementedError(
+                "dataset type %r: only SyntheticSegDataset ships with this build (no dataset is "
+                "available offline); pass an iterable of batches for real data" % t)
+        return SyntheticLoader(samples_per_gpu, tuple(dataset_cfg["size"]),
+                               dataset_cfg.get("num_classes", num_classes), seed=seed,
+                               rank=gdist.rank(), device=device)
+    return dataset_cfg  # already an iterable of batches
+
+
+def train_segmentor(model, train_sampler, val_sampler, dataset, cfg, distributed=False,
+                    validate=False, timestamp=None, meta=None, logger=None):
+    device = torch.device("cuda", torch.cuda.current_device())
+    model = model.to(device)
+    arena = ParamArena(model)
+    reducer = gdist.GradReducer(arena.flat_grad, arena.segments,
+                                bucket_bytes=cfg.get("bucket_bytes", 64 << 20))
+    opt = dict(cfg.optimizer)
+    if opt.pop("type", "SGD") != "SGD":
+        raise NotImplementedError("only SGD (the in-tree config) has a fused arena kernel")
+    lr = opt["lr"]
+    lr_scaler = cfg.get("lr_scaler")      # gaiaseg/apis/train.py:103-113
+    if lr_scaler is not None:
+        total_batch = cfg.data["samples_per_gpu"] * gdist.world_size()
+        if lr_scaler.get("policy", "linear") == "linear":
+            lr = lr_scaler["base_lr"] * total_batch
+        else:
+            lr = lr_scaler["base_lr"] * total_batch ** lr_scaler.get("temperature", 0.5)
+    runner = IterBasedRunner(model, arena, reducer, base_lr=lr, momentum=opt.get("momentum", 0.0),
+                             weight_decay=opt.get("weight_decay", 0.0),
+                             max_iters=cfg.runner["max_iters"], work_dir=cfg.get("work_dir"),
+                             logger=logger, meta=meta)
+    if cfg.get("manipulate_arch", True):  # :142-146
+        runner.register_hook(ManipulateArchHook(train_sampler))
+    lrc = dict(cfg.get("lr_config") or dict(policy="fixed"))
+    policy = lrc.pop("policy", "fixed")
+    runner.register_hook(PolyLrUpdaterHook(**lrc) if policy == "poly" else FixedLrUpdaterHook())
+    if cfg.get("optimizer_config", {}) and dict(cfg.optimizer_config).get("grad_clip"):
+        raise NotImplementedError("grad_clip")
+    runner.register_hook(ArenaOptimizerHook())
+    ck = cfg.get("checkpoint_config")
+    if ck:
+        runner.register_hook(CheckpointHook(**dict(ck)))
+    lg = cfg.get("log_config")
+    if lg:
+        runner.register_hook(TextLoggerHook(interval=lg.get("interval", 50), logger=logger))
+    if validate:
+        # the cross-arch evaluation loop (gaiaseg/core/evaluation/cross_arch_eval_hooks.py) is a
+        # "next" row of SURVEY.md §8f, not part of the forward/backward hot path
+        if logger:
+            logger.warning("validation hooks are not part of this build; continuing without")
+    if cfg.get("resume_from"):
+        runner.resume(cfg.resume_from)
+    elif cfg.get("load_from"):
+        runner.load_checkpoint(cfg.load_from)
+    loader = build_dataloader(dataset, cfg.data["samples_per_gpu"], seed=cfg.get("seed") or 0,
+                              device=device)
+    runner.run([loader], cfg.get("workflow", [("train", 1)]))
+    return runner
