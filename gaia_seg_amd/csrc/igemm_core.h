@@ -75,7 +75,7 @@ struct Tile {
   static constexpr int BV = (BK * BN / 4 + NT - 1) / NT;  // dense float4 per thread
 };
 
-template <int BM, int BN>
+template <int BM, int BN, bool NOREAD = false>
 __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const float* __restrict__ Bs,
                                            f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN],
                                            int wave, int lane) {
@@ -86,9 +86,11 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const f
     const int ko = ks * 4 + kk;
     float a[T::TM], b[T::TN];
 #pragma unroll
-    for (int i = 0; i < T::TM; ++i) a[i] = As[ko * T::PA + 8 * ks + wave * T::WM + i * 16 + li];
+    for (int i = 0; i < T::TM; ++i)
+      a[i] = NOREAD ? (float)(lane + i) : As[ko * T::PA + 8 * ks + wave * T::WM + i * 16 + li];
 #pragma unroll
-    for (int j = 0; j < T::TN; ++j) b[j] = Bs[ko * T::PB + 8 * ks + j * 16 + li];
+    for (int j = 0; j < T::TN; ++j)
+      b[j] = NOREAD ? (float)(lane - j) : Bs[ko * T::PB + 8 * ks + j * 16 + li];
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
@@ -359,7 +361,9 @@ __device__ __forceinline__ void rows_epilogue(
 //  * global loads run TWO K steps ahead of the MFMAs (two register sets), because one K step of
 //    fp32 MFMA work (~1k cycles per wave) is shorter than the gather's memory latency.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, bool BTRANS, int KS>
+// ABL > 0 are timing-only ablation builds used by scratch/kbench.hip (1: no global loads,
+// 2: + no LDS stores, 3: + no LDS reads); the library only instantiates ABL = 0.
+template <int BM, int BN, bool BTRANS, int KS, int ABL = 0>
 __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
   __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
@@ -445,19 +449,27 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     for (int s = 0; s < AS; ++s) {
       const bool ok = kvalid && ((vmask[s] >> tap) & 1u);
       const unsigned off = ok ? (unsigned)(rowoff[s] + aoff) : kOOB;
-      ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
+      if constexpr (ABL >= 1) ra[s] = f32x4{(float)off, 1.f, 2.f, 3.f};
+      else
+        ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
     }
     const int bbase = 4 * (tap * (int)p.d_tap + (BTRANS ? c0 : c0 * p.d_row));
 #pragma unroll
     for (int r = 0; r < T::BV; ++r) {
       const unsigned off = (bok[r] && kvalid) ? (unsigned)(boff[r] + bbase) : kOOB;
-      rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dense, off, 0, 0));
+      if constexpr (ABL >= 1) rb[r] = f32x4{(float)off, 1.f, 2.f, 3.f};
+      else
+        rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dense, off, 0, 0));
     }
     c0 += BK;
     if (c0 >= p.Cs) { c0 = 0; ++tap; }
   };
 
   auto store = [&](const f32x4 (&ra)[AS], const f32x4 (&rb)[T::BV], int buf) {
+    if constexpr (ABL >= 2) {
+      asm volatile("" ::"v"(ra[0][0]), "v"(rb[0][0]));
+      return;
+    }
     float* As = lds + buf * T::STAGE;
     float* Bs = As + T::A_SZ;
 #pragma unroll
@@ -494,13 +506,13 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     for (int i = 0; i < nk; i += 2) {
       // even phase: MFMAs on step i (buf0); set 1 holds step i+1 (in flight); refill set 0 with i+2
       if (i + 2 < nk) load(ra0, rb0);
-      mfma_stage<BM, BN>(buf0, buf0 + T::A_SZ, acc, wave, lane);
+      mfma_stage<BM, BN, (ABL >= 3)>(buf0, buf0 + T::A_SZ, acc, wave, lane);
       if (i + 1 < nk) store(ra1, rb1, 1);
       __syncthreads();
       if (i + 1 >= nk) break;
       // odd phase: MFMAs on step i+1 (buf1); set 0 holds step i+2; refill set 1 with i+3
       if (i + 3 < nk) load(ra1, rb1);
-      mfma_stage<BM, BN>(buf1, buf1 + T::A_SZ, acc, wave, lane);
+      mfma_stage<BM, BN, (ABL >= 3)>(buf1, buf1 + T::A_SZ, acc, wave, lane);
       if (i + 2 < nk) store(ra0, rb0, 0);
       __syncthreads();
     }
@@ -702,8 +714,10 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split) {
   Plan pl{};
   // BN: least padded width, larger tile on ties
   int best = 32, best_pad = 1 << 30;
+  static const int bn_cap = env_int("GS_BN_CAP", 128);
   for (int i = 0; i < 6; ++i) {
     const int bn = kBN[i];
+    if (bn > bn_cap) continue;
     const int pad = (int)ceil_div(Nn, bn) * bn;
     if (pad < best_pad) { best_pad = pad; best = bn; }
   }

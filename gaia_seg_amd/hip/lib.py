@@ -85,6 +85,8 @@ PROTOTYPES = {
     "gs_ce_backward": (_i32, [_CE, _P, _P, _P, _P, _P, _f32, _P, _i32, _P]),
     "gs_ce_label_prob": (_i32, [_CE, _P, _P, _P, _P]),
     "gs_resize_argmax": (_i32, [_CE, _P, _P, _P, _P]),
+    "gs_ohem_workspace_bytes": (_sz, []),
+    "gs_ohem_weights": (_i32, [_P, _i64, _i64, _f32, _i32, _P, _P, _sz, _P]),
     "gs_sgd_step": (_i32, [_P, _P, _P, _i64, _f32, _f32, _f32, _f32, _P]),
 }
 

@@ -5,5 +5,6 @@ from .builder import (BACKBONES, HEADS, LOSSES, NECKS, PIXEL_SAMPLERS, SEGMENTOR
 from .backbones import *  # noqa: F401,F403
 from .decode_heads import *  # noqa: F401,F403
 from .losses import *  # noqa: F401,F403
+from .pixel_samplers import OHEMPixelSampler  # noqa: F401
 from .segmentors import *  # noqa: F401,F403
 from .utils import *  # noqa: F401,F403

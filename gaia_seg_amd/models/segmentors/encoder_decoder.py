@@ -80,19 +80,24 @@ class EncoderDecoder(nn.Module):
         return x
 
     def _resize_logits(self, logits, size):
-        """mmseg.ops.resize(bilinear) of a logits tensor through the HIP kernel (no grad path)."""
-        def runner(tape, acts):
-            return [ops.bilinear(tape, acts[0], size, self.align_corners)]
-        a = logits
-        c = a.shape[1]
-        if c % 4 != 0:
-            # class dimension padded to a float4 multiple: the kernels move whole float4s
-            a4 = Act.from_nchw(logits, requires_grad=False)
-            full = Act(a4.t.as_strided((a4.N, a4.H, a4.W, a4.ld), a4.t.stride()), False)
-            tape = ops_tape_disabled()
-            out = ops.bilinear(tape, full, size, self.align_corners)
-            return out.t[..., :c].permute(0, 3, 1, 2)
-        return tape_function(runner, [a], False)[0]
+        """mmseg.ops.resize(bilinear) of a logits tensor through the HIP kernel (no grad path).
+        The class dimension is padded to a float4 multiple (the kernels move whole float4s)."""
+        from ...hip.runtime import Tape, round_up
+        n, c, h, w = logits.shape
+        size = (int(size[0]), int(size[1]))
+        if size == (h, w):
+            return logits  # bilinear resize to the same size is the identity
+        ld = round_up(c, 4)
+        nhwc = logits.detach().permute(0, 2, 3, 1)
+        in_place = (nhwc.stride() == (h * w * ld, w * ld, ld, 1) and nhwc.data_ptr() % 16 == 0
+                    and nhwc.untyped_storage().nbytes() // 4 - nhwc.storage_offset() >= n * h * w * ld)
+        if in_place:
+            full = nhwc.as_strided((n, h, w, ld), nhwc.stride())
+        else:
+            full = torch.zeros((n, h, w, ld), dtype=torch.float32, device=logits.device)
+            full[..., :c].copy_(nhwc)
+        out = ops.bilinear(Tape(enabled=False), Act(full, False), size, self.align_corners)
+        return out.t[..., :c].permute(0, 3, 1, 2)
 
     def encode_decode(self, img, img_metas):
         x = self.extract_feat(img)
@@ -179,9 +184,35 @@ class EncoderDecoder(nn.Module):
             output = output.flip(dims=(3,)) if flip_direction == "horizontal" else output.flip(dims=(2,))
         return output
 
+    def _whole_argmax(self, img, img_meta, rescale):
+        """whole_inference + softmax + argmax in one fused kernel: argmax of the bilinearly resized
+        logits straight from the low-resolution head output (softmax is monotone; the 19xHxW
+        tensor never exists).  Valid when the two resizes of the reference (to the input size, then
+        to ori_shape, dynamic_distiller.py:252-262,461-473) collapse into one, i.e. the image was
+        not rescaled; otherwise the generic path below is taken."""
+        import ctypes
+        from ...hip import lib as _lib
+        from ...hip.runtime import current_stream_ptr
+        from ..losses.cross_entropy_loss import _ce_desc
+        x = self.extract_feat(img)
+        logits = self._decode_head_forward_test(x, img_meta)
+        size = tuple(img.shape[2:])
+        d = _ce_desc(logits, size, None, self.align_corners)
+        seg = torch.empty((img.shape[0],) + size, dtype=torch.int64, device=img.device)
+        L = _lib.load()
+        _lib.check(L.gs_resize_argmax(ctypes.byref(d), logits.data_ptr(), seg.data_ptr(), None,
+                                      current_stream_ptr()), "gs_resize_argmax")
+        return seg
+
     def simple_test(self, img, img_meta, rescale=True):
-        seg_logit = self.inference(img, img_meta, rescale)
-        seg_pred = seg_logit.argmax(dim=1)
+        ori = tuple(img_meta[0]["ori_shape"][:2])
+        fused = (self.test_cfg.mode == "whole" and not img_meta[0].get("flip", False)
+                 and (not rescale or ori == tuple(img.shape[2:])))
+        if fused:
+            seg_pred = self._whole_argmax(img, img_meta, rescale)
+        else:
+            seg_logit = self.inference(img, img_meta, rescale)
+            seg_pred = seg_logit.argmax(dim=1)
         return list(seg_pred.cpu().numpy())
 
     def aug_test(self, imgs, img_metas, rescale=True):
@@ -244,7 +275,3 @@ class EncoderDecoder(nn.Module):
                 log_vars[n] = log_vars[n].detach()
         return loss, log_vars
 
-
-def ops_tape_disabled():
-    from ...hip.runtime import Tape
-    return Tape(enabled=False)

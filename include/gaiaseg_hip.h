@@ -234,6 +234,17 @@ int gs_ce_backward(const gs_ce_desc* d, const float* logits, const int64_t* labe
 int gs_ce_label_prob(const gs_ce_desc* d, const float* logits, const int64_t* labels, float* prob,
                      void* stream);
 
+/* OHEMPixelSampler.sample (mmseg): from the label probabilities written by
+ * gs_ce_label_prob, weight[i] = 1 for the hard valid pixels, else 0.
+ *   use_thresh != 0 : threshold = max(thresh, sorted_valid_prob[min(batch_kept, n_valid-1)]),
+ *                     keep prob < threshold          (OHEM with `thresh`)
+ *   use_thresh == 0 : keep the batch_kept valid pixels of smallest probability (= largest loss)
+ * The rank statistic is an exact 3-pass radix select (integer atomics only; reproducible). */
+size_t gs_ohem_workspace_bytes(void);
+int gs_ohem_weights(const float* prob, int64_t n, int64_t batch_kept, float thresh,
+                    int32_t use_thresh, float* weight, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Inference epilogue — K17                                                                    */
 /* ------------------------------------------------------------------------------------------ */

@@ -84,13 +84,13 @@ def randomize(model, seed=0):
                     m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
 
 
-def make_pair(cfg, seed=0):
+def make_pair(cfg, seed=0, ocfg=None):
     """(product model on CPU params — move with .cuda(), oracle on CPU) with equal weights."""
     from gaia_seg_amd.models import build_segmentor
     from oracle.model import OEncoderDecoder
     prod = build_segmentor(copy.deepcopy(cfg))
     randomize(prod, seed)
-    orc = OEncoderDecoder(**{k: v for k, v in copy.deepcopy(cfg).items() if k != "type"})
+    orc = OEncoderDecoder(**{k: v for k, v in copy.deepcopy(ocfg or cfg).items() if k != "type"})
     sd = {k: v.detach().clone().contiguous() for k, v in prod.state_dict().items()}
     missing, unexpected = orc.load_state_dict(sd, strict=True)
     return prod, orc
