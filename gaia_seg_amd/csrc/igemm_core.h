@@ -51,7 +51,24 @@ struct IgemmArgs {
   int accumulate;
   int tiles_m, tiles_n;
   unsigned src_bytes, dense_bytes;  // extents for the bounds-checked buffer loads (0 = unknown)
+  // fast kernel: runtime tap grid (sub-sampled for the parity classes of a strided dgrad)
+  int kh_n, kw_n;           // taps of this launch: kh_n x kw_n (<= 3 x 3)
+  long d_tap_h, d_tap_w;    // dense offset per tap row / tap column
+  // output row lattice: row m = (n, hq, wq) -> pixel (n, hq*o_s + o_ph, wq*o_s + o_pw) of an
+  // o_H x o_W image (o_s == 0: rows are dense pixels)
+  int o_s, o_ph, o_pw, o_Hq, o_Wq, o_H, o_W;
 };
+
+// pixel index of GEMM row m in the output tensor
+__device__ __forceinline__ long out_pixel(const IgemmArgs& p, int m) {
+  if (p.o_s == 0) return m;
+  const int hwq = p.o_Hq * p.o_Wq;
+  const int n = m / hwq;
+  const int rem = m - n * hwq;
+  const int hq = rem / p.o_Wq;
+  const int wq = rem - hq * p.o_Wq;
+  return ((long)n * p.o_H + (hq * p.o_s + p.o_ph)) * p.o_W + (wq * p.o_s + p.o_pw);
+}
 
 // k-major LDS image with skew: element (k, i) at k*P + 8*(k>>2) + i, P % 32 == 16.
 //  * MFMA fragment read (ds_read_b32, lanes 0-31 hold k = 4ks + {0,1}, i = 0..15): rows k and k+1
@@ -341,7 +358,7 @@ __device__ __forceinline__ void rows_epilogue(
         } else {
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
           if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (long)m * p.ld_add + col);
-          float* o = p.out + (long)m * p.ld_out + col;
+          float* o = p.out + out_pixel(p, m) * p.ld_out + col;
           if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
           *reinterpret_cast<f32x4*>(o) = v;
         }
@@ -368,7 +385,8 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
   using T = Tile<BM, BN>;
   __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
   constexpr int AS = BM / 64;
-  constexpr int TAPS = KS * KS;
+  constexpr int MAXTAPS = KS * KS;  // KS only bounds the tap loop and tags the kernel name
+  const int ntaps = p.kh_n * p.kw_n;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int ntiles = p.tiles_m * p.tiles_n;
@@ -404,9 +422,11 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     rowoff[s] = (int)(4 * ((long)n * p.s_n + (long)hb * p.s_h + (long)wb * p.s_w + kq * 4));
     unsigned mk = 0;
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) {
-      const int hi = hb + (tp / KS) * p.step_h, wi = wb + (tp % KS) * p.step_w;
-      const bool ok = rv && (unsigned)hi < (unsigned)p.Hs && (unsigned)wi < (unsigned)p.Ws;
+    for (int tp = 0; tp < MAXTAPS; ++tp) {
+      const int jh = tp / p.kw_n, jw = tp - jh * p.kw_n;
+      const int hi = hb + jh * p.step_h, wi = wb + jw * p.step_w;
+      const bool ok = rv && tp < ntaps && (unsigned)hi < (unsigned)p.Hs &&
+                      (unsigned)wi < (unsigned)p.Ws;
       mk |= (ok ? 1u : 0u) << tp;
     }
     vmask[s] = mk;
@@ -442,8 +462,8 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     for (int j = 0; j < T::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto load = [&](f32x4 (&ra)[AS], f32x4 (&rb)[T::BV]) {
-    const bool kvalid = tap < TAPS;
-    const int kh = tap / KS, kw = tap - kh * KS;
+    const bool kvalid = tap < ntaps;
+    const int kh = tap / p.kw_n, kw = tap - kh * p.kw_n;
     const int aoff = 4 * (kh * p.step_h * (int)p.s_h + kw * p.step_w * (int)p.s_w + c0);
 #pragma unroll
     for (int s = 0; s < AS; ++s) {
@@ -453,7 +473,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
       else
         ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
     }
-    const int bbase = 4 * (tap * (int)p.d_tap + (BTRANS ? c0 : c0 * p.d_row));
+    const int bbase = 4 * (kh * (int)p.d_tap_h + kw * (int)p.d_tap_w + (BTRANS ? c0 : c0 * p.d_row));
 #pragma unroll
     for (int r = 0; r < T::BV; ++r) {
       const unsigned off = (bok[r] && kvalid) ? (unsigned)(boff[r] + bbase) : kOOB;
@@ -684,7 +704,7 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmAr
     } else {
       if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
       if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (long)row * p.ld_add + col);
-      float* o = p.out + (long)row * p.ld_out + col;
+      float* o = p.out + out_pixel(p, row) * p.ld_out + col;
       if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
       *reinterpret_cast<f32x4*>(o) = v;
     }
@@ -824,6 +844,38 @@ static inline void launch_reduce(const IgemmArgs& a, int splits, int rows_are_ta
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, a,
                      splits, rows_are_taps);
 }
+
+// ---- strided dgrad as s*s stride-1 sub-problems (one per input-pixel parity class) ----
+// For input row h = hq*s + ph the taps kh with (ph + pad - kh*dil) % s == 0 contribute, reading
+// dy row hq + (ph + pad - kh*dil)/s.  Those taps form an arithmetic progression, so each class is
+// an ordinary gather-GEMM over a sub-sampled tap grid: no MFMA work is spent on structural zeros
+// (the single-launch form wastes 1 - 1/s^2 of it).
+struct TapAxis {
+  int n;      // number of valid taps
+  int k0;     // first valid tap
+  int dk;     // tap step
+  int off0;   // source offset of the first valid tap
+  int step;   // source offset step per valid tap
+};
+static inline TapAxis tap_axis(int ph, int pad, int dil, int s, int K) {
+  TapAxis a{0, 0, 1, 0, 0};
+  int first = -1, second = -1;
+  for (int k = 0; k < K; ++k) {
+    const int num = ph + pad - k * dil;
+    if (((num % s) + s) % s == 0) {
+      if (first < 0) first = k;
+      else if (second < 0) second = k;
+      ++a.n;
+    }
+  }
+  if (a.n == 0) return a;
+  a.k0 = first;
+  a.dk = second > 0 ? second - first : 1;
+  a.off0 = (ph + pad - first * dil) / s;          // exact division
+  a.step = -(a.dk * dil) / s;
+  return a;
+}
+static inline int class_len(int L, int s, int ph) { return L > ph ? (L - ph + s - 1) / s : 0; }
 
 static inline int ksize_tag(const gs_conv_desc* d) {
   if (d->KH == 1 && d->KW == 1) return 1;

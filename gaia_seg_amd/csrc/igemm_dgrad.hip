@@ -3,6 +3,80 @@
 
 using namespace gs;
 
+// workspace needed by the strided (parity-class) path: max over the classes
+size_t gs_dgrad_strided_slab_bytes(const gs_conv_desc* d) {
+  size_t need = 0;
+  const int s = d->stride;
+  for (int ph = 0; ph < s; ++ph)
+    for (int pw = 0; pw < s; ++pw) {
+      const TapAxis th = tap_axis(ph, d->pad, d->dil, s, d->KH), tw = tap_axis(pw, d->pad, d->dil, s, d->KW);
+      const int Hq = class_len(d->H, s, ph), Wq = class_len(d->W, s, pw);
+      if (!th.n || !tw.n || !Hq || !Wq) continue;
+      const long Mc = (long)d->N * Hq * Wq;
+      const Plan pl = make_plan((int)Mc, d->Ci, th.n * tw.n * d->Co, true);
+      need = std::max(need, slab_bytes(pl, Mc, d->Ci));
+    }
+  return need;
+}
+
+static int dgrad_strided_fast(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
+                              int accumulate, void* workspace, size_t workspace_bytes,
+                              hipStream_t st) {
+  const int s = d->stride, ks = ksize_tag(d);
+  const long d_tap = (long)d->Ci_max * d->Co_ld;
+  bool any_empty = false;
+  for (int ph = 0; ph < s && !any_empty; ++ph)
+    for (int pw = 0; pw < s; ++pw)
+      if (!tap_axis(ph, d->pad, d->dil, s, d->KH).n || !tap_axis(pw, d->pad, d->dil, s, d->KW).n)
+        any_empty = true;
+  if (!accumulate && any_empty) {
+    hipError_t e = hipMemset2DAsync(dx, (size_t)d->x_sw * sizeof(float), 0,
+                                    (size_t)d->Ci * sizeof(float), (size_t)d->N * d->H * d->W, st);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  for (int ph = 0; ph < s; ++ph)
+    for (int pw = 0; pw < s; ++pw) {
+      const TapAxis th = tap_axis(ph, d->pad, d->dil, s, d->KH), tw = tap_axis(pw, d->pad, d->dil, s, d->KW);
+      const int Hq = class_len(d->H, s, ph), Wq = class_len(d->W, s, pw);
+      if (!th.n || !tw.n || !Hq || !Wq) continue;
+      const long Mc = (long)d->N * Hq * Wq;
+      const int ktot = th.n * tw.n * d->Co;
+      const Plan pl = make_plan((int)Mc, d->Ci, ktot, true);
+      const size_t need = slab_bytes(pl, Mc, d->Ci);
+      if (need > workspace_bytes || (need && !workspace)) return GS_E_WORKSPACE;
+      IgemmArgs a{};
+      a.src = dy; a.out = dx; a.slab = need ? static_cast<float*>(workspace) : nullptr;
+      const long tap0 = (long)th.k0 * d->KW + tw.k0;
+      a.dense = w + tap0 * d_tap;
+      a.s_c = 1; a.s_w = d->ldy; a.s_h = (long)d->Wo * d->ldy; a.s_n = (long)d->Ho * a.s_h;
+      a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;
+      a.Hp = Hq; a.Wp = Wq; a.npix = (int)Mc;
+      a.KW = tw.n; a.taps = th.n * tw.n;
+      a.mul_h = a.mul_w = 1; a.base_h = th.off0; a.base_w = tw.off0;
+      a.step_h = th.step; a.step_w = tw.step; a.div_h = a.div_w = 1;
+      a.d_tap = d_tap; a.d_row = d->Co_ld; a.n_lim = d->Ci;
+      a.kh_n = th.n; a.kw_n = tw.n;
+      a.d_tap_h = (long)th.dk * d->KW * d_tap; a.d_tap_w = (long)tw.dk * d_tap;
+      a.M = (int)Mc; a.Nn = d->Ci; a.Ktot = ktot;
+      a.ld_out = (int)d->x_sw;
+      a.nk_total = pl.nk_total; a.nk_per_split = pl.nk_per_split;
+      a.accumulate = accumulate ? 1 : 0; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
+      a.src_bytes = (unsigned)((size_t)d->N * a.s_n * sizeof(float));
+      a.dense_bytes = (unsigned)(((size_t)d->KH * d->KW - tap0) * d_tap * sizeof(float));
+      a.o_s = s; a.o_ph = ph; a.o_pw = pw; a.o_Hq = Hq; a.o_Wq = Wq; a.o_H = d->H; a.o_W = d->W;
+      if (ks == 1) launch_rows_fast<true, 1>(pl, a, st);
+      else launch_rows_fast<true, 3>(pl, a, st);
+      int rc = launch_status();
+      if (rc != GS_OK) return rc;
+      if (pl.splits > 1) {
+        launch_reduce(a, pl.splits, 0, st);
+        rc = launch_status();
+        if (rc != GS_OK) return rc;
+      }
+    }
+  return GS_OK;
+}
+
 extern "C" int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
                                int accumulate, void* workspace, size_t workspace_bytes,
                                void* stream) {
@@ -12,6 +86,15 @@ extern "C" int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const flo
   if (d->x_sc != 1 || (d->Ci & 3) || (d->x_sw & 3)) return GS_E_ALIGN;
   if (d->x_sh != (int64_t)d->W * d->x_sw || d->x_sn != (int64_t)d->H * d->x_sh) return GS_E_BADARG;
   if (!aligned16(dy) || !aligned16(w) || !aligned16(dx)) return GS_E_ALIGN;
+  hipStream_t st = as_stream(stream);
+  {
+    const int ks0 = ksize_tag(d);
+    const size_t sb = (size_t)d->N * d->Ho * d->Wo * d->ldy * sizeof(float);
+    const size_t db = (size_t)d->KH * d->KW * d->Ci_max * d->Co_ld * sizeof(float);
+    if (d->stride > 1 && fast_rows_ok(d->Co, ks0, sb, db) && getenv("GS_NO_FAST") == nullptr &&
+        (long)d->N * d->H * d->W * d->x_sw < (1L << 31))
+      return dgrad_strided_fast(d, dy, w, dx, accumulate, workspace, workspace_bytes, st);
+  }
   const Plan pl = plan_dgrad(d);
   const long M = (long)d->N * d->H * d->W;
   const size_t need = slab_bytes(pl, M, d->Ci);
@@ -30,7 +113,8 @@ extern "C" int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const flo
   a.ld_out = (int)d->x_sw; a.ld_add = 0;
   a.nk_total = pl.nk_total; a.nk_per_split = pl.nk_per_split;
   a.accumulate = accumulate ? 1 : 0; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
-  hipStream_t st = as_stream(stream);
+  a.kh_n = d->KH; a.kw_n = d->KW;
+  a.d_tap_h = (long)d->KW * a.d_tap; a.d_tap_w = a.d_tap;
   const int ks = ksize_tag(d);
   const size_t src_b = (size_t)d->N * a.s_n * sizeof(float);
   const size_t dense_b = (size_t)a.taps * a.d_tap * sizeof(float);

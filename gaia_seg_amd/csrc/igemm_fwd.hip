@@ -3,6 +3,8 @@
 
 using namespace gs;
 
+size_t gs_dgrad_strided_slab_bytes(const gs_conv_desc* d);  // igemm_dgrad.hip
+
 extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
   if (check_desc(d) != GS_OK) return 0;
   size_t b = 0;
@@ -13,6 +15,7 @@ extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
   if (d->x_sc == 1 && (d->Ci & 3) == 0) {
     const Plan pl = plan_dgrad(d);
     b = std::max(b, slab_bytes(pl, (long)d->N * d->H * d->W, d->Ci));
+    if (d->stride > 1) b = std::max(b, gs_dgrad_strided_slab_bytes(d));
   }
   {
     const Plan pl = plan_wgrad(d);
@@ -53,6 +56,8 @@ extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const fl
   a.accumulate = 0; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
   hipStream_t st = as_stream(stream);
   const int ks = ksize_tag(d);
+  a.kh_n = d->KH; a.kw_n = d->KW;
+  a.d_tap_h = (long)d->KW * a.d_tap; a.d_tap_w = a.d_tap;
   const size_t src_b = (size_t)d->N * d->x_sn * sizeof(float);
   const size_t dense_b = (size_t)a.taps * a.d_tap * sizeof(float);
   a.src_bytes = (unsigned)src_b;
