@@ -685,19 +685,205 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_kernel(const IgemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fast wgrad (NHWC source, Ci % 4 == 0): a streaming kernel — at stage 1 it moves 12 KB per K step
+// for 1k cycles of MFMA work, so it lives on bytes in flight.  Same recipe as the fast row kernel:
+// index math hoisted / incremental, bounds-checked buffer loads (no branches), and THREE K steps
+// of global loads in flight (three register sets, statically rotated).
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int KS>
+__global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p) {
+  using T = Tile<BM, BN>;
+  __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
+  constexpr int QA = BM / 4;
+  constexpr int AS = BK * QA / NT;  // 1 (BM = 64) or 2 (BM = 128)
+  constexpr int KSTR = NT / QA;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int i0 = tm * BM, n0 = tn * BN;
+  const int kt0 = blockIdx.y * p.nk_per_split;
+  const int kt1 = min(kt0 + p.nk_per_split, p.nk_total);
+  const int nk = kt1 - kt0;
+
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dense =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dense), 0, p.dense_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0xFFFFFFFFu;
+
+  // this thread's four GEMM rows share one tap (Cs % 4 == 0): constant source offsets
+  const int iq = t % QA, krA = t / QA;
+  const int i = i0 + iq * 4;
+  const bool iv = i < p.M;
+  const int ii = iv ? i : 0;
+  const int tap = ii / p.Cs, c = ii - tap * p.Cs;
+  const int kwid = KS ? KS : p.KW;
+  const int kh = tap / kwid, kw = tap - kh * kwid;
+  const int offh = p.base_h + kh * p.step_h, offw = p.base_w + kw * p.step_w;
+  // pixel state per slot, advanced by BK pixels per K step
+  int pn[AS], ph[AS], pw[AS];
+  const int hw = p.Hp * p.Wp;
+  const int Nb = p.npix / hw;
+#pragma unroll
+  for (int s = 0; s < AS; ++s) {
+    const int m = kt0 * BK + krA + s * KSTR;
+    pn[s] = m / hw;
+    const int rem = m - pn[s] * hw;
+    ph[s] = rem / p.Wp;
+    pw[s] = rem - ph[s] * p.Wp;
+  }
+  // dense operand (dy rows): per-thread constants
+  int brow[T::BV], bcol[T::BV];
+  bool bok[T::BV];
+#pragma unroll
+  for (int r = 0; r < T::BV; ++r) {
+    const int idx = t + NT * r;
+    const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
+    brow[r] = kr;
+    bcol[r] = n0 + nq * 4;
+    bok[r] = idx < BK * BN / 4 && bcol[r] < p.n_lim;
+  }
+  int kt_load = kt0;
+
+  f32x4 acc[T::TM][T::TN];
+#pragma unroll
+  for (int a = 0; a < T::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < T::TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load = [&](f32x4 (&ra)[AS], f32x4 (&rb)[T::BV]) {
+#pragma unroll
+    for (int s = 0; s < AS; ++s) {
+      const int hi = ph[s] * p.mul_h + offh, wi = pw[s] * p.mul_w + offw;
+      const bool ok = iv && pn[s] < Nb && (unsigned)hi < (unsigned)p.Hs && (unsigned)wi < (unsigned)p.Ws;
+      const unsigned off =
+          ok ? 4u * (unsigned)(pn[s] * (int)p.s_n + hi * (int)p.s_h + wi * (int)p.s_w + c) : kOOB;
+      ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
+      // advance this slot by BK pixels
+      pw[s] += BK;
+      while (pw[s] >= p.Wp) { pw[s] -= p.Wp; ++ph[s]; }
+      while (ph[s] >= p.Hp) { ph[s] -= p.Hp; ++pn[s]; }
+    }
+#pragma unroll
+    for (int r = 0; r < T::BV; ++r) {
+      const int m = kt_load * BK + brow[r];
+      const unsigned off = (bok[r] && m < p.npix) ? 4u * (unsigned)(m * p.d_row + bcol[r]) : kOOB;
+      rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dense, off, 0, 0));
+    }
+    ++kt_load;
+  };
+
+  auto store = [&](const f32x4 (&ra)[AS], const f32x4 (&rb)[T::BV], float* buf) {
+    float* As = buf;
+    float* Bs = buf + T::A_SZ;
+#pragma unroll
+    for (int s = 0; s < AS; ++s) {
+      const int kr = krA + s * KSTR;
+      *reinterpret_cast<f32x4*>(&As[kr * T::PA + 8 * (kr >> 2) + iq * 4]) = ra[s];
+    }
+#pragma unroll
+    for (int r = 0; r < T::BV; ++r) {
+      const int idx = t + NT * r;
+      if (idx < BK * BN / 4) {
+        const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
+        *reinterpret_cast<f32x4*>(&Bs[kr * T::PB + 8 * (kr >> 2) + nq * 4]) = rb[r];
+      }
+    }
+  };
+
+  f32x4 ra0[AS], ra1[AS], ra2[AS];
+  f32x4 rb0[T::BV], rb1[T::BV], rb2[T::BV];
+  float* buf0 = lds;
+  float* buf1 = lds + T::STAGE;
+  // step i computes from buf[i&1]; sets hold steps i+1, i+2; the set freed at step i is
+  // refilled with step i+3.  Unrolled by 6 so that buffer parity and set index are static.
+#define GS_WG_PHASE(I, RL_A, RL_B, RS_A, RS_B, BC, BN_)                          \
+  if ((I) < nk) {                                                               \
+    if ((I) + 3 < nk) load(RL_A, RL_B);                                         \
+    mfma_stage<BM, BN>(BC, BC + T::A_SZ, acc, wave, lane);                      \
+    if ((I) + 1 < nk) store(RS_A, RS_B, BN_);                                   \
+    __syncthreads();                                                            \
+  }
+  if (nk > 0) {
+    load(ra0, rb0);
+    if (nk > 1) load(ra1, rb1);
+    if (nk > 2) load(ra2, rb2);
+    store(ra0, rb0, buf0);
+    __syncthreads();
+    for (int ib = 0; ib < nk; ib += 6) {
+      GS_WG_PHASE(ib + 0, ra0, rb0, ra1, rb1, buf0, buf1)
+      GS_WG_PHASE(ib + 1, ra1, rb1, ra2, rb2, buf1, buf0)
+      GS_WG_PHASE(ib + 2, ra2, rb2, ra0, rb0, buf0, buf1)
+      GS_WG_PHASE(ib + 3, ra0, rb0, ra1, rb1, buf1, buf0)
+      GS_WG_PHASE(ib + 4, ra1, rb1, ra2, rb2, buf0, buf1)
+      GS_WG_PHASE(ib + 5, ra2, rb2, ra0, rb0, buf1, buf0)
+    }
+  }
+#undef GS_WG_PHASE
+
+  float* Cs = lds;
+  constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch > 0) __syncthreads();
+    acc_to_lds<BM, BN>(Cs, acc, ch, wave, lane);
+    __syncthreads();
+    constexpr int QPR = T::CCH / 4;
+    for (int idx = t; idx < BM * QPR; idx += NT) {
+      const int row = idx / QPR, q = idx - row * QPR;
+      const int ir = i0 + row;
+      const int col = n0 + ch * T::CCH + q * 4;
+      if (ch * T::CCH + q * 4 < BN && ir < p.M && col < p.Nn) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * T::PC + q * 4]);
+        if (p.slab) {
+          *reinterpret_cast<f32x4*>(p.slab + ((long)blockIdx.y * p.M + ir) * p.Nn + col) = v;
+        } else {
+          const int tp = ir / p.Cs, cc = ir - tp * p.Cs;
+          *reinterpret_cast<f32x4*>(p.out + (long)tp * p.o_tap + (long)cc * p.o_row + col) = v;
+        }
+      }
+    }
+  }
+}
+
 // Fixed-order sum of the split-K partial slabs + epilogue.  rows_are_taps selects the wgrad
 // output addressing.
+// WIDE = false: one thread per output float4 walks the splits (few splits, many outputs).
+// WIDE = true : one wave per output float4, lanes stride over the splits and combine with a fixed
+//               xor butterfly (many splits, few outputs: stage-1 wgrad has 256 splits of a 64x256
+//               tile — the serial form spent 75 us there on 256 dependent-latency loads).
+template <bool WIDE>
 static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, int splits,
-                                                            int rows_are_taps) {
+                                                                   int rows_are_taps) {
   const int qpr = p.Nn / 4;
   const long total = (long)p.M * qpr;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long)gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63;
+  const long first = WIDE ? ((long)blockIdx.x * 4 + (threadIdx.x >> 6))
+                          : ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  const long stride = WIDE ? (long)gridDim.x * 4 : (long)gridDim.x * blockDim.x;
+  for (long idx = first; idx < total; idx += stride) {
     const int row = (int)(idx / qpr);
     const int col = (int)(idx - (long)row * qpr) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(p.slab + (long)row * p.Nn + col);
-    for (int z = 1; z < splits; ++z)
-      v += *reinterpret_cast<const f32x4*>(p.slab + ((long)z * p.M + row) * p.Nn + col);
+    f32x4 v{0.f, 0.f, 0.f, 0.f};
+    if (WIDE) {
+      for (int z = lane; z < splits; z += 64)
+        v += *reinterpret_cast<const f32x4*>(p.slab + ((long)z * p.M + row) * p.Nn + col);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        v[0] += __shfl_xor(v[0], off, 64);
+        v[1] += __shfl_xor(v[1], off, 64);
+        v[2] += __shfl_xor(v[2], off, 64);
+        v[3] += __shfl_xor(v[3], off, 64);
+      }
+      if (lane != 0) continue;
+    } else {
+      v = *reinterpret_cast<const f32x4*>(p.slab + (long)row * p.Nn + col);
+      for (int z = 1; z < splits; ++z)
+        v += *reinterpret_cast<const f32x4*>(p.slab + ((long)z * p.M + row) * p.Nn + col);
+    }
     if (rows_are_taps) {
       const int tap = row / p.Cs, c = row - tap * p.Cs;
       *reinterpret_cast<f32x4*>(p.out + (long)tap * p.o_tap + (long)c * p.o_row + col) = v;
@@ -730,7 +916,7 @@ static int env_int(const char* name, int dflt) {
 static int wg_target() { static const int v = env_int("GS_WG_TARGET", 2 * kNumCU); return v; }
 static int min_ksteps() { static const int v = env_int("GS_MIN_KSTEPS", 4); return v; }
 
-static Plan make_plan(int M, int Nn, int Ktot, bool allow_split) {
+static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits = 64) {
   Plan pl{};
   // BN: least padded width, larger tile on ties
   int best = 32, best_pad = 1 << 30;
@@ -754,7 +940,7 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split) {
     splits = (int)ceil_div(wg_target(), tiles);
     const int max_by_k = pl.nk_total / min_ksteps();
     if (splits > max_by_k) splits = max_by_k;
-    if (splits > 64) splits = 64;
+    if (splits > max_splits) splits = max_splits;
     while (splits > 1 && (size_t)splits * M * Nn * sizeof(float) > kMaxSlabBytes) --splits;
     if (splits < 1) splits = 1;
   }
@@ -795,6 +981,19 @@ static inline bool fast_rows_ok(int cs, int ks, size_t src_bytes, size_t dense_b
          dense_bytes < (1ull << 31);
 }
 
+template <int KS>
+static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
+  const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
+#define GS_WGF(BM_, BN_)                                                                  \
+  if (pl.bm == BM_ && pl.bn == BN_) {                                                     \
+    hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS>), grid, block, 0, st, a);   \
+    return;                                                                               \
+  }
+  GS_WGF(128, 128) GS_WGF(128, 96) GS_WGF(128, 80) GS_WGF(128, 64) GS_WGF(128, 48) GS_WGF(128, 32)
+  GS_WGF(64, 128) GS_WGF(64, 96) GS_WGF(64, 80) GS_WGF(64, 64) GS_WGF(64, 48) GS_WGF(64, 32)
+#undef GS_WGF
+}
+
 template <bool SCALAR, int KS>
 static void launch_wgrad(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
   const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
@@ -833,7 +1032,8 @@ static Plan plan_dgrad(const gs_conv_desc* d) {
   return make_plan(d->N * d->H * d->W, d->Ci, d->KH * d->KW * d->Co, true);
 }
 static Plan plan_wgrad(const gs_conv_desc* d) {
-  return make_plan(d->KH * d->KW * d->Ci, d->Co, d->N * d->Ho * d->Wo, true);
+  // wgrad: K runs over pixels (up to 131072 at stage 1) while M x N is tiny: allow deep split-K
+  return make_plan(d->KH * d->KW * d->Ci, d->Co, d->N * d->Ho * d->Wo, true, 512);
 }
 static size_t slab_bytes(const Plan& pl, long M, int Nn) {
   return pl.splits > 1 ? (size_t)pl.splits * M * Nn * sizeof(float) : 0;
@@ -841,8 +1041,14 @@ static size_t slab_bytes(const Plan& pl, long M, int Nn) {
 
 static inline void launch_reduce(const IgemmArgs& a, int splits, int rows_are_taps, hipStream_t st) {
   const long total = (long)a.M * (a.Nn / 4);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, a,
-                     splits, rows_are_taps);
+  if (splits >= 48) {
+    const int grid = (int)std::min<long>(ceil_div(total, 4), (long)kNumCU * 16);
+    hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(grid), dim3(256), 0, st, a, splits,
+                       rows_are_taps);
+  } else {
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(stream_grid(total, 256)), dim3(256), 0, st,
+                       a, splits, rows_are_taps);
+  }
 }
 
 // ---- strided dgrad as s*s stride-1 sub-problems (one per input-pixel parity class) ----

@@ -31,7 +31,16 @@ extern "C" int gs_conv2d_wgrad(const gs_conv_desc* d, const float* x, const floa
   a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n;
   hipStream_t st = as_stream(stream);
   const int ks = ksize_tag(d);
-  if (!vec) launch_wgrad<true, 0>(pl, a, st);
+  const size_t src_b = (size_t)d->N * d->x_sn * sizeof(float);
+  const size_t dense_b = (size_t)a.npix * d->ldy * sizeof(float);
+  a.src_bytes = (unsigned)src_b;
+  a.dense_bytes = (unsigned)dense_b;
+  const bool fast = vec && src_b < (1ull << 31) && dense_b < (1ull << 31) &&
+                    getenv("GS_NO_FAST") == nullptr;
+  if (fast && ks == 1) launch_wgrad_fast<1>(pl, a, st);
+  else if (fast && ks == 3) launch_wgrad_fast<3>(pl, a, st);
+  else if (fast) launch_wgrad_fast<0>(pl, a, st);
+  else if (!vec) launch_wgrad<true, 0>(pl, a, st);
   else if (ks == 1) launch_wgrad<false, 1>(pl, a, st);
   else if (ks == 3) launch_wgrad<false, 3>(pl, a, st);
   else launch_wgrad<false, 0>(pl, a, st);
