@@ -375,7 +375,7 @@ __device__ __forceinline__ void rows_epilogue(
 //  * the per-row gather is hoisted out of the K loop: one base pointer and one tap-validity
 //    bit mask per row slot, so a K step costs a mask test and one add per load (the general
 //    kernel spent ~100 VALU + ~60 SALU instructions per K step on index math, r01 ISA census);
-//  * global loads run TWO K steps ahead of the MFMAs (two register sets), because one K step of
+//  * global loads run THREE K steps ahead of the MFMAs (three register sets), because one K step of
 //    fp32 MFMA work (~1k cycles per wave) is shorter than the gather's memory latency.
 // ------------------------------------------------------------------------------------------
 // ABL > 0 are timing-only ablation builds used by scratch/kbench.hip (1: no global loads,
@@ -514,29 +514,35 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     }
   };
 
-  f32x4 ra0[AS], ra1[AS];
-  f32x4 rb0[T::BV], rb1[T::BV];
+  f32x4 ra0[AS], ra1[AS], ra2[AS];
+  f32x4 rb0[T::BV], rb1[T::BV], rb2[T::BV];
   float* buf0 = lds;
   float* buf1 = lds + T::STAGE;
+  // step i computes from buf[i&1]; two register sets hold steps i+1 and i+2 (in flight); the set
+  // freed at step i is refilled with step i+3.  Unrolled by 6: buffer parity and set index static.
+#define GS_ROW_PHASE(I, RL_A, RL_B, RS_A, RS_B, BC, BI)                                   \
+  if ((I) < nk) {                                                                        \
+    if ((I) + 3 < nk) load(RL_A, RL_B);                                                  \
+    mfma_stage<BM, BN, (ABL >= 3)>(BC, BC + T::A_SZ, acc, wave, lane);                   \
+    if ((I) + 1 < nk) store(RS_A, RS_B, BI);                                             \
+    __syncthreads();                                                                     \
+  }
   if (nk > 0) {
     load(ra0, rb0);
     if (nk > 1) load(ra1, rb1);
+    if (nk > 2) load(ra2, rb2);
     store(ra0, rb0, 0);
     __syncthreads();
-    for (int i = 0; i < nk; i += 2) {
-      // even phase: MFMAs on step i (buf0); set 1 holds step i+1 (in flight); refill set 0 with i+2
-      if (i + 2 < nk) load(ra0, rb0);
-      mfma_stage<BM, BN, (ABL >= 3)>(buf0, buf0 + T::A_SZ, acc, wave, lane);
-      if (i + 1 < nk) store(ra1, rb1, 1);
-      __syncthreads();
-      if (i + 1 >= nk) break;
-      // odd phase: MFMAs on step i+1 (buf1); set 0 holds step i+2; refill set 1 with i+3
-      if (i + 3 < nk) load(ra1, rb1);
-      mfma_stage<BM, BN, (ABL >= 3)>(buf1, buf1 + T::A_SZ, acc, wave, lane);
-      if (i + 2 < nk) store(ra0, rb0, 0);
-      __syncthreads();
+    for (int ib = 0; ib < nk; ib += 6) {
+      GS_ROW_PHASE(ib + 0, ra0, rb0, ra1, rb1, buf0, 1)
+      GS_ROW_PHASE(ib + 1, ra1, rb1, ra2, rb2, buf1, 0)
+      GS_ROW_PHASE(ib + 2, ra2, rb2, ra0, rb0, buf0, 1)
+      GS_ROW_PHASE(ib + 3, ra0, rb0, ra1, rb1, buf1, 0)
+      GS_ROW_PHASE(ib + 4, ra1, rb1, ra2, rb2, buf0, 1)
+      GS_ROW_PHASE(ib + 5, ra2, rb2, ra0, rb0, buf1, 0)
     }
   }
+#undef GS_ROW_PHASE
   rows_epilogue<BM, BN>(p, lds, acc, m0, n0, t, wave, lane);
 }
 
@@ -930,9 +936,16 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
   pl.bn = best;
   pl.tiles_n = (int)ceil_div(Nn, pl.bn);
   pl.nk_total = (int)ceil_div(Ktot, BK);
-  // BM: 128 when that still fills the chip, else 64
+  // BM: 128-row tiles run ~15 % faster per FLOP than 64-row ones (each wave owns two 16-row
+  // MFMA tiles per B fragment), so prefer them whenever tiles x attainable K-splits still
+  // fills the chip; parallelism then comes from split-K (r01 sweep: s3/s4 3x3 +12 %, FCN head
+  // conv 82 -> 100 TF).
   const long t128 = ceil_div(M, 128) * pl.tiles_n;
-  pl.bm = (t128 >= wg_target()) ? 128 : 64;
+  const long can_split = allow_split ? std::min<long>(max_splits, std::max(1, pl.nk_total / min_ksteps())) : 1;
+  static const int force_bm = env_int("GS_FORCE_BM", 0);
+  const long pad128 = ceil_div(M, 128) * 128, pad64 = ceil_div(M, 64) * 64;
+  const bool wasteful = pad128 * 100 > pad64 * 115;  // e.g. M = 64 rows of a stage-1 1x1 wgrad
+  pl.bm = force_bm ? force_bm : ((t128 * can_split >= wg_target() && !wasteful) ? 128 : 64);
   pl.tiles_m = (int)ceil_div(M, pl.bm);
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   int splits = 1;
