@@ -47,6 +47,18 @@ def parse_args():
     return ap.parse_args()
 
 
+def k3_traffic():
+    """HBM bytes per K3 launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
+    rocprofv3 --pmc runs of this script; see profiles/r01_k3_traffic.json).  Counters cannot be
+    read from inside the process, so this is the committed measurement, or None."""
+    path = os.path.join(ROOT, "profiles", "r01_k3_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, size, seed):
     """One fwd+bwd+SGD step of the oracle on the host cores: a bounded sample (bs 1, R50 anchor)."""
     import torch
@@ -205,7 +217,7 @@ def main():
                               "forward, incl. its split-K reduce where used)",
                     "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": k3_traffic(),
                     "launches": launches, "avg_launch_us": round(1e3 * ms / launches, 2),
                     "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
                 }

@@ -19,16 +19,17 @@ def short(name):
 
 
 def group(name):
-    if "igemm_rows_fast_kernel" in name or "igemm_rows_kernel" in name:
+    if "igemm_rows_fast_kernel" in name:     # <BM, BN, BTRANS, KS, ABL>
         t = name.split("<")[1].split(">")[0].split(", ")
-        fast = "fast" in name
-        btrans = t[2] == "true"
-        ks = t[-1]
-        kind = "conv dgrad" if btrans else "conv forward"
-        return "%s %s" % (kind, {"1": "1x1", "3": "3x3"}.get(ks, "other/stem"))
-    if "igemm_wgrad" in name:
+        kind = "conv dgrad" if t[2] == "true" else "conv forward"
+        return "%s %s" % (kind, {"1": "1x1", "3": "3x3"}.get(t[3], "other"))
+    if "igemm_rows_kernel" in name:          # <BM, BN, BTRANS, DIVS, SCALAR, KS>
+        t = name.split("<")[1].split(">")[0].split(", ")
+        kind = "conv dgrad" if t[2] == "true" else "conv forward"
+        return "%s %s" % (kind, {"1": "1x1", "3": "3x3"}.get(t[5], "stem/other"))
+    if "igemm_wgrad" in name:                # <BM, BN, KS> or <BM, BN, SCALAR, KS>
         ks = name.split("<")[1].split(">")[0].split(", ")[-1]
-        return "conv wgrad %s" % {"1": "1x1", "3": "3x3"}.get(ks, "other/stem")
+        return "conv wgrad %s" % {"1": "1x1", "3": "3x3"}.get(ks, "stem/other")
     if "splitk_reduce" in name:
         return "split-K reduce"
     if re.search(r"bn_|sum_partials|colsum", name):
