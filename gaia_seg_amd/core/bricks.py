@@ -461,11 +461,9 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
                     m.manipulate_width(width * self.expansion)
 
     def forward_act(self, tape, x):
-        out = self.conv1.forward_act(tape, x)
-        out = self.norm1.forward_act(tape, out, relu=True)
-        out = self.conv2.forward_act(tape, out, tag="k3")  # the roofline kernel (SURVEY.md K3)
-        out = self.norm2.forward_act(tape, out, relu=True)
-        out = self.conv3.forward_act(tape, out)
+        # the shortcut branch is evaluated first so that, in the reversed backward replay, its
+        # strided dgrad ACCUMULATES into x.g after conv1's dgrad wrote it: the parity classes of a
+        # stride-2 1x1 conv that have no tap then need no zero fill at all
         identity = x
         if self.downsample is not None:
             for m in self.downsample:
@@ -476,6 +474,11 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
                 else:
                     raise NotImplementedError(
                         "downsample member %s (avg_down) has no HIP kernel yet" % type(m).__name__)
+        out = self.conv1.forward_act(tape, x)
+        out = self.norm1.forward_act(tape, out, relu=True)
+        out = self.conv2.forward_act(tape, out, tag="k3")  # the roofline kernel (SURVEY.md K3)
+        out = self.norm2.forward_act(tape, out, relu=True)
+        out = self.conv3.forward_act(tape, out)
         return self.norm3.forward_act(tape, out, relu=True, residual=identity)
 
     def forward(self, x):

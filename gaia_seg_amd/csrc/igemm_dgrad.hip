@@ -30,8 +30,14 @@ static int dgrad_strided_fast(const gs_conv_desc* d, const float* dy, const floa
       if (!tap_axis(ph, d->pad, d->dil, s, d->KH).n || !tap_axis(pw, d->pad, d->dil, s, d->KW).n)
         any_empty = true;
   if (!accumulate && any_empty) {
-    hipError_t e = hipMemset2DAsync(dx, (size_t)d->x_sw * sizeof(float), 0,
-                                    (size_t)d->Ci * sizeof(float), (size_t)d->N * d->H * d->W, st);
+    // classes without taps (e.g. 3 of the 4 classes of a 1x1 stride-2 conv) stay zero.  A dense dx is
+    // cleared with the 1-D memset (a fill kernel); hipMemset2DAsync is staged through ~30 buffer
+    // copies per call on ROCm 7.2 (seen in the r01 trace) and is kept for sliced dx only.
+    const size_t rows = (size_t)d->N * d->H * d->W;
+    hipError_t e = (d->x_sw == d->Ci)
+                       ? hipMemsetAsync(dx, 0, rows * d->Ci * sizeof(float), st)
+                       : hipMemset2DAsync(dx, (size_t)d->x_sw * sizeof(float), 0,
+                                          (size_t)d->Ci * sizeof(float), rows, st);
     if (e != hipSuccess) return static_cast<int>(e);
   }
   for (int ph = 0; ph < s; ++ph)
