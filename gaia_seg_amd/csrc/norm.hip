@@ -128,6 +128,52 @@ static inline void launch_sum_partials(const float* part, int nparts, int width,
                      copy_src, copy_n);
 }
 
+// Local-BN fast path: fixed-order sum of the partials + finalize in one launch (one wave per
+// channel quad; after the xor butterfly every lane holds the totals, lanes 0..3 finish one
+// channel each).  Saves one launch per BN layer per step versus sum_partials + bn_finalize.
+__global__ __launch_bounds__(256) void bn_sum_finalize_kernel(
+    const float* __restrict__ part, int nparts, int C, const float* __restrict__ x, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* running_mean, float* running_var, float* __restrict__ coeffs) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q * 4 >= C) return;
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = lane; p < nparts; p += 64) {
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(part + (long)p * 2 * C + q * 4);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(part + (long)p * 2 * C + C + q * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] += v1[e]; a[4 + e] += v2[e]; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += __shfl_xor(a[e], off, 64);
+  if (lane < 4) {
+    const int c = q * 4 + lane;
+    double s1 = a[0], s2 = a[4];
+    if (lane == 1) { s1 = a[1]; s2 = a[5]; }
+    if (lane == 2) { s1 = a[2]; s2 = a[6]; }
+    if (lane == 3) { s1 = a[3]; s2 = a[7]; }
+    // the partial sums were rounded to float when stored, exactly as in the two-launch path
+    const double d1 = (double)(float)s1 / count;
+    const double mean = (double)x[c] + d1;
+    double var = (double)(float)s2 / count - d1 * d1;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f;
+    coeffs[c] = (float)((double)g * invstd);
+    coeffs[C + c] = beta ? beta[c] : 0.f;
+    coeffs[2 * C + c] = (float)mean;
+    coeffs[3 * C + c] = (float)invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
 // coeffs: [0,C) scale = gamma*invstd ; [C,2C) beta ; [2C,3C) mean ; [3C,4C) invstd
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums,
                                                           double count, int C,
@@ -365,6 +411,26 @@ extern "C" int gs_bn_stats(const float* x, int64_t rows, int32_t C, int32_t ldx,
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(g.gx, g.gy), dim3(256), 0, st, x, (long)rows, C,
                      ldx, g.rows_per_block, part);
   launch_sum_partials(part, g.gx, 2 * C, sums, x, C, st);  // sums = {S1, S2, shift = x[0, :]}
+  return launch_status();
+}
+
+extern "C" int gs_bn_stats_finalize(const float* x, int64_t rows, int32_t C, int32_t ldx,
+                                    const float* gamma, const float* beta, float eps,
+                                    float momentum, float* running_mean, float* running_var,
+                                    float* coeffs, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  int rc = check_rows(x, rows, C, ldx);
+  if (rc) return rc;
+  if (!coeffs || !workspace) return GS_E_NULL;
+  const RedGeom g = red_geom(rows, C);
+  if ((size_t)g.gx * 2 * C * sizeof(float) > workspace_bytes) return GS_E_WORKSPACE;
+  if (!aligned16(workspace)) return GS_E_ALIGN;
+  hipStream_t st = as_stream(stream);
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(g.gx, g.gy), dim3(256), 0, st, x, (long)rows, C,
+                     ldx, g.rows_per_block, part);
+  hipLaunchKernelGGL(bn_sum_finalize_kernel, dim3((C / 4 + 3) / 4), dim3(256), 0, st, part, g.gx, C,
+                     x, (double)rows, gamma, beta, eps, momentum, running_mean, running_var, coeffs);
   return launch_status();
 }
 

@@ -227,16 +227,20 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
                              "size %s" % (tuple(x.t.shape),))
         nb = L.gs_bn_stats_workspace_bytes(rows, C)
         ws = _ws.get(nb, dev)
-        _lib.check(L.gs_bn_stats(x.ptr, rows, C, x.ld, sums.data_ptr(), ws.data_ptr(), ws.numel(),
-                                 st), "gs_bn_stats")
-        if bn.process_group is not None:
-            merged, count = _sync_stats(sums, count, C, bn.process_group)
-            sums = merged
         rm = bn.running_mean.data_ptr() if (bn.running_mean is not None and bn.training) else None
         rv = bn.running_var.data_ptr() if (bn.running_var is not None and bn.training) else None
         mom = bn.momentum if bn.momentum is not None else 0.1
-        _lib.check(L.gs_bn_finalize(sums.data_ptr(), count, C, gamma, beta, bn.eps, mom, rm, rv,
-                                    coeffs.data_ptr(), st), "gs_bn_finalize")
+        if bn.process_group is None:
+            # rank-local statistics: partial sums + (sum, finalize) in two launches
+            _lib.check(L.gs_bn_stats_finalize(x.ptr, rows, C, x.ld, gamma, beta, bn.eps, mom, rm, rv,
+                                              coeffs.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                       "gs_bn_stats_finalize")
+        else:
+            _lib.check(L.gs_bn_stats(x.ptr, rows, C, x.ld, sums.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), st), "gs_bn_stats")
+            merged, count = _sync_stats(sums, count, C, bn.process_group)
+            _lib.check(L.gs_bn_finalize(merged.data_ptr(), count, C, gamma, beta, bn.eps, mom, rm,
+                                        rv, coeffs.data_ptr(), st), "gs_bn_finalize")
         if bn.training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked()  # host-side counter: no device op per BN per step
     else:

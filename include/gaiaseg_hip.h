@@ -112,6 +112,12 @@ int gs_bn_stats(const float* x, int64_t rows, int32_t C, int32_t ldx, float* sum
 int gs_bn_finalize(const float* sums, double count, int32_t C, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, float* coeffs, void* stream);
+/* gs_bn_stats + gs_bn_finalize in two launches instead of three, for rank-local statistics
+ * (count = rows).  Bit-identical to the separate calls. */
+int gs_bn_stats_finalize(const float* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, float* coeffs, void* workspace,
+                         size_t workspace_bytes, void* stream);
 /* Eval-mode coefficients from running statistics (norm_eval / inference). coeffs as above. */
 int gs_bn_eval_coeffs(const float* running_mean, const float* running_var, int32_t C,
                       const float* gamma, const float* beta, float eps, float* coeffs,
