@@ -47,6 +47,19 @@ def parse_args():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU cores this process may actually use: the cgroup quota if there is one (the GPU box
+    gives 16 of its 256 hardware threads), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def k3_traffic():
     """HBM bytes per K3 launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
     rocprofv3 --pmc runs of this script; see profiles/r01_k3_traffic.json).  Counters cannot be
@@ -75,7 +88,8 @@ def cpu_baseline(cfg, size, seed):
     orc.manipulate_arch(fold_dict(r50)["arch"])
     opt = torch.optim.SGD(orc.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
     batch = make_batch(1, h, w, seed=seed)
-    cores = torch.get_num_threads()
+    cores = host_cores()
+    torch.set_num_threads(cores)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -196,9 +210,10 @@ def main():
             "dtype": "fp32",
             "data": "synthetic",
             "config": {
-                "workload": "FCN + aux FCN on the dynamic R50..R101 ResNet supernet (BASELINE "
-                            "configs[1]), %dx%d crops, bs %d/GPU, arch=%s, fwd+bwd+SGD, "
-                            "random-init weights" % (size[1], size[0], bs, args.arch),
+                "workload": "%s + aux FCN on the dynamic R50..R101 ResNet supernet (%s), %dx%d "
+                            "crops, bs %d/GPU, arch=%s, fwd+bwd+SGD, random-init weights"
+                            % (cfg.model["decode_head"]["type"], os.path.basename(args.config),
+                               size[1], size[0], bs, args.arch),
                 "global_batch": world * bs,
                 "parallelism": "dp%d" % world,
                 "last_loss": round(loss, 5),
