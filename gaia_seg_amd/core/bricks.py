@@ -160,7 +160,7 @@ class DynamicConv2d(nn.Module, DynamicMixin):
     def forward_act(self, tape, x, out=None, tag=None):
         self._check_layout()
         if getattr(self, "_deploying", False):
-            self._deploy_slice(x.C)
+            self._deploy_slice(x.t.shape[1] if x.nchw_image else x.C)
         return ops.conv2d(tape, x, self.weight, self.bias, self.width_state, self.stride,
                           self.padding, self.dilation, out=out, tag=tag)
 

@@ -23,6 +23,10 @@ _ALIGN = 64  # floats: 256-byte aligned segments (float4 loads need 16 B; keep c
 
 class ParamArena:
     def __init__(self, model):
+        from .bricks import DynamicConv2d, relayout_conv_params
+        for m in model.modules():  # (re)attach the physical-layout descriptors (lost by deepcopy)
+            if isinstance(m, DynamicConv2d):
+                relayout_conv_params(m)
         params = [(n, p) for n, p in model.named_parameters()]
         if not params:
             raise ValueError("model has no parameters")
