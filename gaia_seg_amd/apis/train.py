@@ -86,11 +86,17 @@ def train_segmentor(model, train_sampler, val_sampler, dataset, cfg, distributed
     lg = cfg.get("log_config")
     if lg:
         runner.register_hook(TextLoggerHook(interval=lg.get("interval", 50), logger=logger))
-    if validate:
-        # the cross-arch evaluation loop (gaiaseg/core/evaluation/cross_arch_eval_hooks.py) is a
-        # "next" row of SURVEY.md §8f, not part of the forward/backward hot path
-        if logger:
-            logger.warning("validation hooks are not part of this build; continuing without")
+    if validate and cfg.get("evaluation"):
+        # gaiaseg/apis/train.py:150-170: (Dist)CrossArchEvalHook over the val anchors
+        from ..core.evaluation import CrossArchEvalHook
+        ev = dict(cfg.evaluation)
+        val_cfg = cfg.data.get("val") or cfg.data["train"]
+        val_loader = build_dataloader(val_cfg, cfg.data["samples_per_gpu"], seed=12345,
+                                      device=device)
+        runner.register_hook(CrossArchEvalHook(val_loader, val_sampler,
+                                               interval=ev.get("interval", 8000),
+                                               num_batches=ev.get("num_batches", 4),
+                                               num_classes=model.num_classes, logger=logger))
     if cfg.get("resume_from"):
         runner.resume(cfg.resume_from)
     elif cfg.get("load_from"):

@@ -127,3 +127,49 @@ extern "C" int gs_ohem_weights(const float* prob, int64_t n, int64_t batch_kept,
                      use_thresh, weight);
   return launch_status();
 }
+
+// ------------------------------------------------------------------------------------------
+// mIoU support: confusion matrix of predictions vs labels (mmseg `intersect_and_union` /
+// dataset.evaluate(metric='mIoU'), driven by gaiaseg/core/evaluation/cross_arch_eval_hooks.py:85-92
+// through mmseg's multi_gpu_test).  conf[label * C + pred] += 1 for labels != ignore_index.
+// LDS-privatised integer atomics, exact and order-independent.
+// ------------------------------------------------------------------------------------------
+namespace gs {
+constexpr int kMaxLdsBins = 8192;
+__global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restrict__ pred,
+                                                        const int64_t* __restrict__ label, long n,
+                                                        int C, int ignore,
+                                                        unsigned long long* __restrict__ conf) {
+  __shared__ unsigned sh[kMaxLdsBins];
+  const int bins = C * C;
+  const bool use_lds = bins <= kMaxLdsBins;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < bins; i += 256) sh[i] = 0;
+    __syncthreads();
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const long l = label[i], p = pred[i];
+    if (l == ignore || l < 0 || l >= C || p < 0 || p >= C) continue;
+    const int b = (int)l * C + (int)p;
+    if (use_lds) atomicAdd(&sh[b], 1u);
+    else atomicAdd(&conf[b], 1ull);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += 256)
+      if (sh[i]) atomicAdd(&conf[i], (unsigned long long)sh[i]);
+  }
+}
+}  // namespace gs
+
+extern "C" int gs_confusion_matrix(const int64_t* pred, const int64_t* label, int64_t n,
+                                   int32_t num_classes, int32_t ignore_index, uint64_t* conf,
+                                   void* stream) {
+  if (!pred || !label || !conf) return GS_E_NULL;
+  if (n <= 0 || num_classes <= 0 || num_classes > 4096) return GS_E_BADARG;
+  hipLaunchKernelGGL(gs::confusion_kernel, dim3(gs::stream_grid(n, 256)), dim3(256), 0,
+                     gs::as_stream(stream), pred, label, (long)n, num_classes, ignore_index,
+                     reinterpret_cast<unsigned long long*>(conf));
+  return gs::launch_status();
+}

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "gs_resize_argmax": (_i32, [_CE, _P, _P, _P, _P]),
     "gs_ohem_workspace_bytes": (_sz, []),
     "gs_ohem_weights": (_i32, [_P, _i64, _i64, _f32, _i32, _P, _P, _sz, _P]),
+    "gs_confusion_matrix": (_i32, [_P, _P, _i64, _i32, _i32, _P, _P]),
     "gs_sgd_step": (_i32, [_P, _P, _P, _i64, _f32, _f32, _f32, _f32, _P]),
 }
 

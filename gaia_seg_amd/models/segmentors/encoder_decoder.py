@@ -31,8 +31,9 @@ class EncoderDecoder(nn.Module):
             self.neck = builder.build_neck(neck)
         self._init_decode_head(decode_head)
         self._init_auxiliary_head(auxiliary_head)
-        self.train_cfg = train_cfg
-        self.test_cfg = test_cfg
+        from ...core.config import ConfigDict
+        self.train_cfg = ConfigDict(train_cfg) if isinstance(train_cfg, dict) else train_cfg
+        self.test_cfg = ConfigDict(test_cfg) if isinstance(test_cfg, dict) else test_cfg
         self.init_weights(pretrained=pretrained)
         assert self.with_decode_head
 
@@ -203,6 +204,15 @@ class EncoderDecoder(nn.Module):
         _lib.check(L.gs_resize_argmax(ctypes.byref(d), logits.data_ptr(), seg.data_ptr(), None,
                                       current_stream_ptr()), "gs_resize_argmax")
         return seg
+
+    def simple_test_device(self, img, img_meta, rescale=True):
+        """simple_test that keeps the label map on the device: int64 [N, H, W]."""
+        ori = tuple(img_meta[0]["ori_shape"][:2])
+        fused = (self.test_cfg.mode == "whole" and not img_meta[0].get("flip", False)
+                 and (not rescale or ori == tuple(img.shape[2:])))
+        if fused:
+            return self._whole_argmax(img, img_meta, rescale)
+        return self.inference(img, img_meta, rescale).argmax(dim=1)
 
     def simple_test(self, img, img_meta, rescale=True):
         ori = tuple(img_meta[0]["ori_shape"][:2])

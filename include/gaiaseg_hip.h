@@ -260,6 +260,13 @@ int gs_ohem_weights(const float* prob, int64_t n, int64_t batch_kept, float thre
 int gs_resize_argmax(const gs_ce_desc* d, const float* logits, int64_t* seg, float* probs,
                      void* stream);
 
+/* mIoU evaluation support: conf[label*C + pred] += 1 over the pixels
+ * whose label != ignore_index; conf is [C*C] uint64, accumulated (zero it before the first call).
+ * Replaces mmseg's intersect_and_union histogramming behind
+ * gaiaseg/core/evaluation/cross_arch_eval_hooks.py:85-92. */
+int gs_confusion_matrix(const int64_t* pred, const int64_t* label, int64_t n, int32_t num_classes,
+                        int32_t ignore_index, uint64_t* conf, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Optimiser — K18                                                                             */
 /* ------------------------------------------------------------------------------------------ */
