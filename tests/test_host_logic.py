@@ -147,3 +147,19 @@ def test_grad_reducer_plan_covers_active_ranges_once():
     for p in reversed(active):
         p._gs_grad_ready(p)
     red.finish()                                               # world size 1: nothing to wait for
+
+
+def test_closed_form_flops_match_baseline_table(psp_model):
+    """BASELINE.md §2 (OS32, 512x1024, per image): backbone GF (3x3 part) and params."""
+    from gaia_seg_amd.core.flops import model_flops
+    want = {"MIN": (34.8, 14.9, 9.73, 17.0, 7.3), "R50": (85.4, 38.7, 23.51, 19.4, 9.7),
+            "R101": (163.0, 79.7, 42.50, 19.4, 9.7), "MAX": (324.2, 162.3, 84.78, 21.9, 12.1)}
+    cfg = Config.fromfile(CFG)
+    anchors = {a["name"]: a for a in build_model_sampler(cfg.train_sampler).model_samplers[0].anchors}
+    for name, (b, k3, params, psp, aux) in want.items():
+        psp_model.manipulate_arch(fold_dict(anchors[name])["arch"])
+        f = model_flops(psp_model, 512, 1024)
+        assert abs(f["backbone"] / 1e9 - b) < 0.06, (name, f["backbone"] / 1e9)
+        assert abs(f["backbone_3x3"] / 1e9 - k3) < 0.06
+        assert abs(f["backbone_params"] / 1e6 - params) < 0.02
+        assert abs(f["decode"] / 1e9 - psp) < 0.06 and abs(f["aux"] / 1e9 - aux) < 0.06
