@@ -228,7 +228,7 @@ def main():
                 launches, ms, flops = summ
                 achieved = flops / (ms * 1e-3) / 1e12
                 out["roofline"] = {
-                    "kernel": "igemm_rows_fast_kernel<BM,BN,false,3> (dynamic 3x3 bottleneck conv "
+                    "kernel": "igemm_rows_fast_kernel<BM,BN,false,3,0,1> + splitk_reduce_kernel<false,1> (dynamic 3x3 bottleneck conv "
                               "forward, incl. its split-K reduce where used)",
                     "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -380,7 +380,16 @@ __device__ __forceinline__ void rows_epilogue(
 // ------------------------------------------------------------------------------------------
 // ABL > 0 are timing-only ablation builds used by scratch/kbench.hip (1: no global loads,
 // 2: + no LDS stores, 3: + no LDS reads); the library only instantiates ABL = 0.
-template <int BM, int BN, bool BTRANS, int KS, int ABL = 0>
+// ABL == 9 is a diagnostic build (scratch/kbench.hip): s_memtime stamps around the sections of
+// every phase, written per wave to p.slab as 8 x uint64.
+__device__ __forceinline__ unsigned long long gs_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+// ROLE only names the instantiation (gs_conv_desc::role): role 1 = the bottleneck conv2 (K3), so
+// that rocprofv3 attributes the headline kernel separately from the other 3x3 convolutions.
+template <int BM, int BN, bool BTRANS, int KS, int ABL = 0, int ROLE = 0, bool PIPE = true>
 __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
   __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     for (int s = 0; s < AS; ++s) {
       const bool ok = kvalid && ((vmask[s] >> tap) & 1u);
       const unsigned off = ok ? (unsigned)(rowoff[s] + aoff) : kOOB;
-      if constexpr (ABL >= 1) ra[s] = f32x4{(float)off, 1.f, 2.f, 3.f};
+      if constexpr (ABL >= 1 && ABL != 9) ra[s] = f32x4{(float)off, 1.f, 2.f, 3.f};
       else
         ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
     }
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
 #pragma unroll
     for (int r = 0; r < T::BV; ++r) {
       const unsigned off = (bok[r] && kvalid) ? (unsigned)(boff[r] + bbase) : kOOB;
-      if constexpr (ABL >= 1) rb[r] = f32x4{(float)off, 1.f, 2.f, 3.f};
+      if constexpr (ABL >= 1 && ABL != 9) rb[r] = f32x4{(float)off, 1.f, 2.f, 3.f};
       else
         rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dense, off, 0, 0));
     }
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
   };
 
   auto store = [&](const f32x4 (&ra)[AS], const f32x4 (&rb)[T::BV], int buf) {
-    if constexpr (ABL >= 2) {
+    if constexpr (ABL >= 2 && ABL != 9) {
       asm volatile("" ::"v"(ra[0][0]), "v"(rb[0][0]));
       return;
     }
@@ -518,14 +527,164 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
   f32x4 rb0[T::BV], rb1[T::BV], rb2[T::BV];
   float* buf0 = lds;
   float* buf1 = lds + T::STAGE;
+  unsigned long long st_k0 = 0, st_l0 = 0, st_l1 = 0, d_load = 0, d_mfma = 0, d_store = 0, d_bar = 0;
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  (void)s0; (void)s1; (void)s2; (void)s3; (void)s4; (void)d_load; (void)d_mfma; (void)d_store; (void)d_bar;
+#define GS_STAMP(x) if constexpr (ABL == 9) { x = gs_stamp(); }
+  if constexpr (ABL == 9) st_k0 = __builtin_amdgcn_s_memrealtime();
+  if constexpr (PIPE) {
+    // ---- software-pipelined K loop -------------------------------------------------------
+    // One wave can run only ONE MFMA ahead of its instruction stream, so everything else a K step
+    // needs (fragment reads of the next k-group, the gather's address math + global loads for
+    // step i+3, the LDS stores of step i+1) is issued in the ~24 free issue cycles behind each
+    // 32-cycle MFMA instead of in serial sections between MFMA bursts (r01 stamps: 2465 cycles
+    // per K step for 1024 cycles of MFMA work per wave; MFMA pipe 75 % busy at 2 waves/SIMD).
+    // sched_barrier(0) after every slot pins the hand-placed order.
+    constexpr int NQ = T::TM * T::TN;            // MFMAs per k-group
+    const int kk = lane >> 4, li = lane & 15;
+    const int a_base = kk * T::PA + wave * T::WM + li;
+    const int b_base = kk * T::PB + li;
+    float fa[2][T::TM], fb[2][T::TN];
+    auto read_a = [&](const float* buf, int g, float (&a)[T::TM]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+        a[i] = (ABL >= 3 && ABL != 9) ? (float)(lane + i + g) : buf[a_base + g * (4 * T::PA + 8) + i * 16];
+    };
+    auto read_b = [&](const float* buf, int g, float (&b)[T::TN]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j)
+        b[j] = (ABL >= 3 && ABL != 9) ? (float)(lane - j - g)
+                                      : buf[T::A_SZ + b_base + g * (4 * T::PB + 8) + j * 16];
+    };
+    // scalar K-step state of the NEXT stage to load (no divisions in the loop)
+    const int a_step_h = 4 * p.step_h * (int)p.s_h, a_step_w = 4 * p.step_w * (int)p.s_w;
+    const int b_step_h = 4 * (int)p.d_tap_h, b_step_w = 4 * (int)p.d_tap_w;
+    const int b_cstep = BTRANS ? 4 * BK : 4 * BK * p.d_row;
+    int kh = tap / p.kw_n, kw = tap - kh * p.kw_n;
+    int aoff = kh * a_step_h + kw * a_step_w + 4 * c0;
+    int bbase = kh * b_step_h + kw * b_step_w + (BTRANS ? 4 * c0 : 4 * c0 * p.d_row);
+    unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
+    int k_left = nk;
+    auto load_a = [&](f32x4 (&ra)[AS]) __attribute__((always_inline)) {
+      const bool kvalid = k_left > 0;
+#pragma unroll
+      for (int s = 0; s < AS; ++s) {
+        const bool ok = kvalid && (vmask[s] & tapbit) != 0;
+        const unsigned off = ok ? (unsigned)(rowoff[s] + aoff) : kOOB;
+        if constexpr (ABL >= 1 && ABL != 9) ra[s] = f32x4{(float)off, 1.f, 2.f, 3.f};
+        else
+          ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
+      }
+    };
+    auto load_b = [&](f32x4 (&rb)[T::BV]) __attribute__((always_inline)) {
+      const bool kvalid = k_left > 0;
+#pragma unroll
+      for (int r = 0; r < T::BV; ++r) {
+        const unsigned off = (bok[r] && kvalid) ? (unsigned)(boff[r] + bbase) : kOOB;
+        if constexpr (ABL >= 1 && ABL != 9) rb[r] = f32x4{(float)off, 1.f, 2.f, 3.f};
+        else
+          rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dense, off, 0, 0));
+      }
+      // advance to the following K step
+      --k_left;
+      const int nc0 = c0 + BK;
+      const bool wrap = nc0 >= p.Cs;          // next K step starts a new tap
+      const int nkw = kw + 1;
+      const bool wrapw = nkw >= p.kw_n;
+      kh += (wrap && wrapw) ? 1 : 0;
+      kw = wrap ? (wrapw ? 0 : nkw) : kw;
+      c0 = wrap ? 0 : nc0;
+      tapbit = wrap ? (tapbit << 1) : tapbit;
+      aoff = wrap ? kh * a_step_h + kw * a_step_w : aoff + 4 * BK;
+      bbase = wrap ? kh * b_step_h + kw * b_step_w : bbase + b_cstep;
+    };
+    auto store_a = [&](const f32x4 (&ra)[AS], float* As) __attribute__((always_inline)) {
+      if constexpr (ABL >= 2 && ABL != 9) { asm volatile("" ::"v"(ra[0][0])); return; }
+#pragma unroll
+      for (int s = 0; s < AS; ++s) {
+        const int row = (t >> 2) + 64 * s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * T::PA + 8 * kq + row] = ra[s][j];
+      }
+    };
+    auto store_b = [&](const f32x4 (&rb)[T::BV], float* Bs) __attribute__((always_inline)) {
+      if constexpr (ABL >= 2 && ABL != 9) { asm volatile("" ::"v"(rb[0][0])); return; }
+#pragma unroll
+      for (int r = 0; r < T::BV; ++r) {
+        const int idx = t + NT * r;
+        if ((r + 1) * NT <= BK * BN / 4 || idx < BK * BN / 4) {
+          if constexpr (!BTRANS) {
+            const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
+            *reinterpret_cast<f32x4*>(&Bs[kr * T::PB + 8 * (kr >> 2) + nq * 4]) = rb[r];
+          } else {
+            const int nrow = idx >> 2, kq2 = idx & 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs[(kq2 * 4 + j) * T::PB + 8 * kq2 + nrow] = rb[r][j];
+          }
+        }
+      }
+    };
+    // slots (index of the MFMA within its k-group) behind which the side work is issued
+    constexpr int Q_RB = NQ > 1 ? 1 : 0, Q_LA = NQ > 2 ? 2 : NQ - 1, Q_LB = NQ > 4 ? 4 : NQ - 1;
+    auto phase = [&](f32x4 (&rla)[AS], f32x4 (&rlb)[T::BV], const f32x4 (&rsa)[AS],
+                     const f32x4 (&rsb)[T::BV], const float* bc, float* bn)
+                     __attribute__((always_inline)) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cur = g & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int i = q / T::TN, j = q - i * T::TN;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+          if (g < 3 && q == 0) read_a(bc, g + 1, fa[nxt]);
+          if (g < 3 && q == Q_RB) read_b(bc, g + 1, fb[nxt]);
+          if (g == 0 && q == Q_LA) load_a(rla);
+          if (g == 0 && q == Q_LB) load_b(rlb);
+          if (g == 2 && q == Q_LA) store_a(rsa, bn);
+          if (g == 2 && q == Q_LB) store_b(rsb, bn + T::A_SZ);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (ABL < 4 || ABL == 9) __syncthreads();
+      read_a(bn, 0, fa[0]);
+      read_b(bn, 0, fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nk > 0) {
+      load_a(ra0); load_b(rb0);
+      load_a(ra1); load_b(rb1);
+      load_a(ra2); load_b(rb2);
+      store_a(ra0, buf0); store_b(rb0, buf0 + T::A_SZ);
+      __syncthreads();
+      read_a(buf0, 0, fa[0]);
+      read_b(buf0, 0, fb[0]);
+      GS_STAMP(st_l0)
+      for (int ib = 0; ib < nk; ib += 6) {
+        if (ib + 0 < nk) phase(ra0, rb0, ra1, rb1, buf0, buf1);
+        if (ib + 1 < nk) phase(ra1, rb1, ra2, rb2, buf1, buf0);
+        if (ib + 2 < nk) phase(ra2, rb2, ra0, rb0, buf0, buf1);
+        if (ib + 3 < nk) phase(ra0, rb0, ra1, rb1, buf1, buf0);
+        if (ib + 4 < nk) phase(ra1, rb1, ra2, rb2, buf0, buf1);
+        if (ib + 5 < nk) phase(ra2, rb2, ra0, rb0, buf1, buf0);
+      }
+    }
+  } else {
   // step i computes from buf[i&1]; two register sets hold steps i+1 and i+2 (in flight); the set
   // freed at step i is refilled with step i+3.  Unrolled by 6: buffer parity and set index static.
 #define GS_ROW_PHASE(I, RL_A, RL_B, RS_A, RS_B, BC, BI)                                   \
   if ((I) < nk) {                                                                        \
+    GS_STAMP(s0)                                                                         \
     if ((I) + 3 < nk) load(RL_A, RL_B);                                                  \
-    mfma_stage<BM, BN, (ABL >= 3)>(BC, BC + T::A_SZ, acc, wave, lane);                   \
+    GS_STAMP(s1)                                                                         \
+    mfma_stage<BM, BN, (ABL >= 3 && ABL != 9)>(BC, BC + T::A_SZ, acc, wave, lane);       \
+    GS_STAMP(s2)                                                                         \
     if ((I) + 1 < nk) store(RS_A, RS_B, BI);                                             \
+    GS_STAMP(s3)                                                                         \
     __syncthreads();                                                                     \
+    GS_STAMP(s4)                                                                         \
+    if constexpr (ABL == 9) {                                                            \
+      d_load += s1 - s0; d_mfma += s2 - s1; d_store += s3 - s2; d_bar += s4 - s3;        \
+    }                                                                                    \
   }
   if (nk > 0) {
     load(ra0, rb0);
@@ -533,6 +692,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     if (nk > 2) load(ra2, rb2);
     store(ra0, rb0, 0);
     __syncthreads();
+    GS_STAMP(st_l0)
     for (int ib = 0; ib < nk; ib += 6) {
       GS_ROW_PHASE(ib + 0, ra0, rb0, ra1, rb1, buf0, 1)
       GS_ROW_PHASE(ib + 1, ra1, rb1, ra2, rb2, buf1, 0)
@@ -542,8 +702,24 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
       GS_ROW_PHASE(ib + 5, ra2, rb2, ra0, rb0, buf1, 0)
     }
   }
+  }
 #undef GS_ROW_PHASE
-  rows_epilogue<BM, BN>(p, lds, acc, m0, n0, t, wave, lane);
+  GS_STAMP(st_l1)
+  if constexpr (ABL == 9) {
+    float* keep = p.slab;
+    IgemmArgs q = p;
+    q.slab = nullptr;
+    rows_epilogue<BM, BN>(q, lds, acc, m0, n0, t, wave, lane);
+    const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(keep) + ((long)blockIdx.x * 4 + wave) * 8;
+      o[0] = st_k0; o[1] = st_l1 - st_l0; o[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32) | __builtin_amdgcn_s_getreg(63508); o[3] = r_end;
+      o[4] = d_load; o[5] = d_mfma; o[6] = d_store; o[7] = d_bar;
+    }
+  } else {
+    rows_epilogue<BM, BN>(p, lds, acc, m0, n0, t, wave, lane);
+  }
+#undef GS_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -861,7 +1037,7 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
 // WIDE = true : one wave per output float4, lanes stride over the splits and combine with a fixed
 //               xor butterfly (many splits, few outputs: stage-1 wgrad has 256 splits of a 64x256
 //               tile — the serial form spent 75 us there on 256 dependent-latency loads).
-template <bool WIDE>
+template <bool WIDE, int ROLE = 0>
 static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, int splits,
                                                                    int rows_are_taps) {
   const int qpr = p.Nn / 4;
@@ -919,10 +1095,13 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
+static bool wg_target_forced() { static const bool v = getenv("GS_WG_TARGET") != nullptr; return v; }
 static int wg_target() { static const int v = env_int("GS_WG_TARGET", 2 * kNumCU); return v; }
+static int dyn_lds() { static const int v = env_int("GS_DYN_LDS", 0); return v; }
 static int min_ksteps() { static const int v = env_int("GS_MIN_KSTEPS", 4); return v; }
 
-static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits = 64) {
+static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits = 64,
+                      bool pipelined = true) {
   Plan pl{};
   // BN: least padded width, larger tile on ties
   int best = 32, best_pad = 1 << 30;
@@ -941,16 +1120,26 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
   // fills the chip; parallelism then comes from split-K (r01 sweep: s3/s4 3x3 +12 %, FCN head
   // conv 82 -> 100 TF).
   const long t128 = ceil_div(M, 128) * pl.tiles_n;
+  // Workgroups a launch should reach.  The software-pipelined row kernels keep the MFMA pipe fed
+  // with ONE wave per SIMD, so one workgroup per CU is enough; two per CU still run ~8 % faster
+  // per FLOP, which only pays while the K range left to each workgroup stays long compared with the
+  // split-K slab it must then write and the reduce must re-read (r01 sweep: s3 1x1 dgrad 41.6 ->
+  // 28.0 us unsplit, FCN-head 3x3 188 vs 200 us with 16 instead of 8 splits).
+  long target = wg_target();
+  if (pipelined && !wg_target_forced()) {
+    const long s_hi = std::max<long>(1, ceil_div(2L * kNumCU, t128));
+    target = (pl.nk_total / s_hi >= 48) ? 2 * kNumCU : kNumCU;
+  }
   const long can_split = allow_split ? std::min<long>(max_splits, std::max(1, pl.nk_total / min_ksteps())) : 1;
   static const int force_bm = env_int("GS_FORCE_BM", 0);
   const long pad128 = ceil_div(M, 128) * 128, pad64 = ceil_div(M, 64) * 64;
   const bool wasteful = pad128 * 100 > pad64 * 115;  // e.g. M = 64 rows of a stage-1 1x1 wgrad
-  pl.bm = force_bm ? force_bm : ((t128 * can_split >= wg_target() && !wasteful) ? 128 : 64);
+  pl.bm = force_bm ? force_bm : ((t128 * can_split >= target && !wasteful) ? 128 : 64);
   pl.tiles_m = (int)ceil_div(M, pl.bm);
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   int splits = 1;
-  if (allow_split && tiles < wg_target() && pl.nk_total >= 2 * min_ksteps()) {
-    splits = (int)ceil_div(wg_target(), tiles);
+  if (allow_split && tiles < target && pl.nk_total >= 2 * min_ksteps()) {
+    splits = (int)ceil_div(target, tiles);
     const int max_by_k = pl.nk_total / min_ksteps();
     if (splits > max_by_k) splits = max_by_k;
     if (splits > max_splits) splits = max_splits;
@@ -975,12 +1164,12 @@ static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
 #undef GS_ROWS
 }
 
-template <bool BTRANS, int KS>
+template <bool BTRANS, int KS, int ROLE = 0>
 static void launch_rows_fast(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
   const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
 #define GS_FAST(BM_, BN_)                                                                  \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                      \
-    hipLaunchKernelGGL((igemm_rows_fast_kernel<BM_, BN_, BTRANS, KS>), grid, block, 0, st, a); \
+    hipLaunchKernelGGL((igemm_rows_fast_kernel<BM_, BN_, BTRANS, KS, 0, ROLE>), grid, block, dyn_lds(), st, a); \
     return;                                                                                \
   }
   GS_FAST(128, 128) GS_FAST(128, 96) GS_FAST(128, 80) GS_FAST(128, 64) GS_FAST(128, 48) GS_FAST(128, 32)
@@ -999,7 +1188,7 @@ static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a, hipStream_t st
   const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
 #define GS_WGF(BM_, BN_)                                                                  \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                     \
-    hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS>), grid, block, 0, st, a);   \
+    hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS>), grid, block, dyn_lds(), st, a);   \
     return;                                                                               \
   }
   GS_WGF(128, 128) GS_WGF(128, 96) GS_WGF(128, 80) GS_WGF(128, 64) GS_WGF(128, 48) GS_WGF(128, 32)
@@ -1024,6 +1213,7 @@ static int check_desc(const gs_conv_desc* d) {
   if (!d) return GS_E_NULL;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Ci <= 0 || d->Co <= 0) return GS_E_BADARG;
   if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0) return GS_E_BADARG;
+  if (d->role < 0 || d->role > GS_CONV_ROLE_BOTTLENECK3X3 || d->reserved != 0) return GS_E_BADARG;
   if (d->Ci > d->Ci_max || d->Co > d->Co_ld) return GS_E_BADARG;
   if ((d->Co & 3) || (d->Co_ld & 3) || (d->ldy & 3) || d->ldy < d->Co) return GS_E_ALIGN;
   const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
@@ -1046,15 +1236,19 @@ static Plan plan_dgrad(const gs_conv_desc* d) {
 }
 static Plan plan_wgrad(const gs_conv_desc* d) {
   // wgrad: K runs over pixels (up to 131072 at stage 1) while M x N is tiny: allow deep split-K
-  return make_plan(d->KH * d->KW * d->Ci, d->Co, d->N * d->Ho * d->Wo, true, 512);
+  return make_plan(d->KH * d->KW * d->Ci, d->Co, d->N * d->Ho * d->Wo, true, 512, false);
 }
 static size_t slab_bytes(const Plan& pl, long M, int Nn) {
   return pl.splits > 1 ? (size_t)pl.splits * M * Nn * sizeof(float) : 0;
 }
 
-static inline void launch_reduce(const IgemmArgs& a, int splits, int rows_are_taps, hipStream_t st) {
+static inline void launch_reduce(const IgemmArgs& a, int splits, int rows_are_taps, hipStream_t st,
+                                 int role = 0) {
   const long total = (long)a.M * (a.Nn / 4);
-  if (splits >= 48) {
+  if (role == 1 && splits < 48) {
+    hipLaunchKernelGGL((splitk_reduce_kernel<false, 1>), dim3(stream_grid(total, 256)), dim3(256), 0,
+                       st, a, splits, rows_are_taps);
+  } else if (splits >= 48) {
     const int grid = (int)std::min<long>(ceil_div(total, 4), (long)kNumCU * 16);
     hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(grid), dim3(256), 0, st, a, splits,
                        rows_are_taps);

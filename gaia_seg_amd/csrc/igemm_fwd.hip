@@ -65,6 +65,7 @@ extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const fl
   const bool fast = vec && fast_rows_ok(d->Ci, ks, src_b, dense_b) && getenv("GS_NO_FAST") == nullptr;
   if (!vec) launch_rows<false, false, true, 0>(pl, a, st);
   else if (fast && ks == 1) launch_rows_fast<false, 1>(pl, a, st);
+  else if (fast && ks == 3 && d->role == GS_CONV_ROLE_BOTTLENECK3X3) launch_rows_fast<false, 3, 1>(pl, a, st);
   else if (fast && ks == 3) launch_rows_fast<false, 3>(pl, a, st);
   else if (ks == 1) launch_rows<false, false, false, 1>(pl, a, st);
   else if (ks == 3) launch_rows<false, false, false, 3>(pl, a, st);
@@ -72,7 +73,7 @@ extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const fl
   rc = launch_status();
   if (rc != GS_OK) return rc;
   if (pl.splits > 1) {
-    launch_reduce(a, pl.splits, 0, st);
+    launch_reduce(a, pl.splits, 0, st, d->role == GS_CONV_ROLE_BOTTLENECK3X3 ? 1 : 0);
     rc = launch_status();
   }
   return rc;

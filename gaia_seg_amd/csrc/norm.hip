@@ -85,70 +85,91 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// out[0..width) = sum over partial rows of part[p][width].  One wave per column quad: the 64
-// lanes stride over the partial rows (independent 16-B loads in flight), accumulate in double
-// and combine with a fixed xor-butterfly, so the result is bit-reproducible.  (A first version
-// used one thread per column walking up to 1024 partials serially: 150 us per call, half of the
-// GPU time of a training step in the r01 profile.)
+// Fixed-order block sum of NV column quads over the partial rows: thread t takes rows t, t+256, ...
+// (four independent 16-B loads in flight per quad), accumulates in double, the wave combines with
+// an xor butterfly and the four wave totals are added in wave order, so the result is
+// bit-reproducible.  After the call every thread holds the totals.  (History: one thread per
+// column walking 1024 partials serially cost 150 us per call; one WAVE per quad still chained
+// 16 dependent-latency iterations, 12 us; this form is launch-latency bound.)
+template <int NV>
+__device__ __forceinline__ void block_sum_quads(const float* __restrict__ part, int nparts,
+                                                long stride, const int (&col)[NV],
+                                                double (&a)[4 * NV], double* sh /* [4][4*NV] */) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int e = 0; e < 4 * NV; ++e) a[e] = 0.0;
+  for (int base = 0; base < nparts; base += 1024) {
+    f32x4 v[4][NV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = base + u * 256 + t;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        v[u][j] = p < nparts ? *reinterpret_cast<const f32x4*>(part + (long)p * stride + col[j])
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[4 * j + e] += v[u][j][e];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int e = 0; e < 4 * NV; ++e) a[e] += __shfl_xor(a[e], off, 64);
+  if (lane == 0)
+#pragma unroll
+    for (int e = 0; e < 4 * NV; ++e) sh[wave * 4 * NV + e] = a[e];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4 * NV; ++e)
+    a[e] = ((sh[e] + sh[4 * NV + e]) + sh[8 * NV + e]) + sh[12 * NV + e];
+}
+
+// out[0..width) = sum over partial rows of part[p][width]; one block per column quad.
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part,
                                                            int nparts, int width,
                                                            float* __restrict__ out,
                                                            const float* __restrict__ copy_src,
                                                            int copy_n) {
-  const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);  // column quad of this wave
+  __shared__ double sh[16];
   // optional tail copy out[width + i] = copy_src[i] (the BN conditioning shift = row 0 of x)
   if (copy_src) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < copy_n) out[width + i] = copy_src[i];
   }
-  if (q * 4 >= width) return;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  for (int p = lane; p < nparts; p += 64) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(part + (long)p * width + q * 4);
-    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a0 += __shfl_xor(a0, off, 64);
-    a1 += __shfl_xor(a1, off, 64);
-    a2 += __shfl_xor(a2, off, 64);
-    a3 += __shfl_xor(a3, off, 64);
-  }
-  if (lane == 0)
-    *reinterpret_cast<f32x4*>(out + q * 4) = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
+  const int q = blockIdx.x;
+  if (q * 4 >= width) return;   // block-uniform
+  const int col[1] = {q * 4};
+  double a[4];
+  block_sum_quads<1>(part, nparts, width, col, a, sh);
+  if (threadIdx.x == 0)
+    *reinterpret_cast<f32x4*>(out + q * 4) = f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
 }
 
 static inline void launch_sum_partials(const float* part, int nparts, int width, float* out,
                                        const float* copy_src, int copy_n, hipStream_t st) {
-  const int quads = width / 4;
-  int grid = (quads + 3) / 4;
+  int grid = width / 4;
   if (copy_src) grid = std::max(grid, (copy_n + 255) / 256);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(grid), dim3(256), 0, st, part, nparts, width, out,
                      copy_src, copy_n);
 }
 
-// Local-BN fast path: fixed-order sum of the partials + finalize in one launch (one wave per
-// channel quad; after the xor butterfly every lane holds the totals, lanes 0..3 finish one
-// channel each).  Saves one launch per BN layer per step versus sum_partials + bn_finalize.
+// Local-BN fast path: fixed-order sum of the partials + finalize in one launch (one block per
+// channel quad; threads 0..3 finish one channel each).  Saves one launch per BN layer per step
+// versus sum_partials + bn_finalize.
 __global__ __launch_bounds__(256) void bn_sum_finalize_kernel(
     const float* __restrict__ part, int nparts, int C, const float* __restrict__ x, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* running_mean, float* running_var, float* __restrict__ coeffs) {
-  const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q * 4 >= C) return;
-  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int p = lane; p < nparts; p += 64) {
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(part + (long)p * 2 * C + q * 4);
-    const f32x4 v2 = *reinterpret_cast<const f32x4*>(part + (long)p * 2 * C + C + q * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { a[e] += v1[e]; a[4 + e] += v2[e]; }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] += __shfl_xor(a[e], off, 64);
+  __shared__ double sh[32];
+  const int q = blockIdx.x;
+  const int col[2] = {q * 4, C + q * 4};
+  double a[8];
+  block_sum_quads<2>(part, nparts, 2L * C, col, a, sh);
+  const int lane = threadIdx.x;
   if (lane < 4) {
     const int c = q * 4 + lane;
     double s1 = a[0], s2 = a[4];
@@ -429,7 +450,7 @@ extern "C" int gs_bn_stats_finalize(const float* x, int64_t rows, int32_t C, int
   float* part = static_cast<float*>(workspace);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(g.gx, g.gy), dim3(256), 0, st, x, (long)rows, C,
                      ldx, g.rows_per_block, part);
-  hipLaunchKernelGGL(bn_sum_finalize_kernel, dim3((C / 4 + 3) / 4), dim3(256), 0, st, part, g.gx, C,
+  hipLaunchKernelGGL(bn_sum_finalize_kernel, dim3(C / 4), dim3(256), 0, st, part, g.gx, C,
                      x, (double)rows, gamma, beta, eps, momentum, running_mean, running_var, coeffs);
   return launch_status();
 }

@@ -48,8 +48,6 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restric
 __global__ __launch_bounds__(256) void select_scan_kernel(unsigned* __restrict__ hist, int pass,
                                                           long long k_req, SelectState* st) {
   __shared__ long long cum[kBins];
-  __shared__ int found;
-  if (threadIdx.x == 0) found = -1;
   for (int i = threadIdx.x; i < kBins; i += 256) cum[i] = hist[i];
   __syncthreads();
   if (threadIdx.x == 0) {  // 2048-element serial prefix sum: ~2 us, runs three times per call

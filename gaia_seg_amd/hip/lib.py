@@ -16,7 +16,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgaiaseg_hip.so")
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HipLibraryError(RuntimeError):
@@ -29,7 +29,8 @@ class ConvDesc(Structure):
                 ("Ci_max", c_int32), ("Co_ld", c_int32), ("KH", c_int32), ("KW", c_int32),
                 ("stride", c_int32), ("pad", c_int32), ("dil", c_int32), ("Ho", c_int32),
                 ("Wo", c_int32), ("x_sn", c_int64), ("x_sh", c_int64), ("x_sw", c_int64),
-                ("x_sc", c_int64), ("ldy", c_int32), ("ld_add", c_int32)]
+                ("x_sc", c_int64), ("ldy", c_int32), ("ld_add", c_int32),
+                ("role", c_int32), ("reserved", c_int32)]
 
 
 class CeDesc(Structure):

@@ -46,7 +46,7 @@ def conv_out_size(h, k, s, p, d):
     return (h + 2 * p - d * (k - 1) - 1) // s + 1
 
 
-def _conv_desc(x, weight, co, stride, pad, dil, ldy, ld_add=0):
+def _conv_desc(x, weight, co, stride, pad, dil, ldy, ld_add=0, role=0):
     """gs_conv_desc for activation ``x`` and a max-size weight Parameter (logical OIHW, physical
     HWIO with row pitch ``Co_ld``)."""
     co_max, ci_max, kh, kw = weight.shape
@@ -64,6 +64,7 @@ def _conv_desc(x, weight, co, stride, pad, dil, ldy, ld_add=0):
     d.Ho = conv_out_size(h, kh, stride, pad, dil)
     d.Wo = conv_out_size(w, kw, stride, pad, dil)
     d.ldy, d.ld_add = ldy, ld_add
+    d.role = role
     if c > ci_max:
         raise ValueError("input has %d channels, conv supports at most %d" % (c, ci_max))
     return d
@@ -113,7 +114,7 @@ def conv2d(tape, x, weight, bias, co, stride=1, pad=0, dil=1, out=None, tag=None
     ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(w, kw, stride, pad, dil)
     if out is None:
         out = Act.empty(n, ho, wo, co, dev)
-    d = _conv_desc(x, weight, co_eff, stride, pad, dil, out.ld)
+    d = _conv_desc(x, weight, co_eff, stride, pad, dil, out.ld, role=1 if tag == "k3" else 0)
     need = L.gs_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _ws.get(need, dev)
     st = current_stream_ptr()

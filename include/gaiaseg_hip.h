@@ -62,7 +62,16 @@ typedef struct gs_conv_desc {
   int64_t x_sn, x_sh, x_sw, x_sc; /* element strides of x (NHWC: x_sc = 1; image: NCHW)     */
   int32_t ldy;            /* pixel stride of y / dy (>= Co, % 4 == 0)                        */
   int32_t ld_add;         /* pixel stride of the optional addend (0 if unused)               */
+  int32_t role;           /* GS_CONV_ROLE_*: profiling label only, results are identical     */
+  int32_t reserved;       /* must be 0                                                       */
 } gs_conv_desc;
+/* role = GS_CONV_ROLE_BOTTLENECK3X3 marks conv2 of DynamicBottleneck (SURVEY.md K3,
+ * gaiaseg/models/utils/dynamic_res_layer.py:96-106): the forward dispatches an identically compiled
+ * but separately NAMED kernel instantiation (igemm_rows_fast_kernel<..., 1> and
+ * splitk_reduce_kernel<false, 1>), so a rocprofv3 kernel trace reports the headline kernel of
+ * bench.py's roofline on its own rows. */
+#define GS_CONV_ROLE_GENERIC 0
+#define GS_CONV_ROLE_BOTTLENECK3X3 1
 
 /* bytes of split-K scratch the three calls below may use for this descriptor (max of the three) */
 size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d);

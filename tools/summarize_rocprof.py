@@ -10,6 +10,10 @@ import shutil
 import sys
 
 
+K3 = "K3: bottleneck conv2 3x3 forward (role 1)"
+K3_RED = "K3: its split-K reduce (role 1)"
+
+
 def short(name):
     name = re.sub(r"^void ", "", name)
     name = name.replace("gs::", "")
@@ -21,6 +25,8 @@ def short(name):
 def group(name):
     if "igemm_rows_fast_kernel" in name:     # <BM, BN, BTRANS, KS, ABL>
         t = name.split("<")[1].split(">")[0].split(", ")
+        if len(t) > 5 and t[5] == "1":
+            return K3
         kind = "conv dgrad" if t[2] == "true" else "conv forward"
         return "%s %s" % (kind, {"1": "1x1", "3": "3x3"}.get(t[3], "other"))
     if "igemm_rows_kernel" in name:          # <BM, BN, BTRANS, DIVS, SCALAR, KS>
@@ -30,6 +36,8 @@ def group(name):
     if "igemm_wgrad" in name:                # <BM, BN, KS> or <BM, BN, SCALAR, KS>
         ks = name.split("<")[1].split(">")[0].split(", ")[-1]
         return "conv wgrad %s" % {"1": "1x1", "3": "3x3"}.get(ks, "stem/other")
+    if "splitk_reduce_kernel<false, 1>" in name:
+        return K3_RED
     if "splitk_reduce" in name:
         return "split-K reduce"
     if re.search(r"bn_|sum_partials|colsum", name):
@@ -59,6 +67,12 @@ def main():
         f.write("total kernel time %.3f ms" % (total / 1e6))
         if steps:
             f.write(" over %d steps = %.3f ms/step" % (steps, total / 1e6 / steps))
+        if K3 in groups:
+            t, c = groups[K3]
+            tr, cr = groups.get(K3_RED, (0.0, 0))
+            f.write("\n\n## headline kernel (bench.py `roofline`)\n\nK3 launches %d, conv kernel avg %.2f us, "
+                    "split-K reduce avg %.2f us over %d reduces; **conv + reduce per K3 launch = %.2f us**"
+                    % (c, t / c / 1e3, (tr / cr / 1e3) if cr else 0.0, cr, (t + tr) / c / 1e3))
         f.write("\n\n## by operator group\n\n| group | % | total ms | calls |\n|---|---|---|---|\n")
         for k, (t, c) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
             f.write("| %s | %.2f | %.3f | %d |\n" % (k, 100 * t / total, t / 1e6, c))
