@@ -1100,9 +1100,54 @@ static int wg_target() { static const int v = env_int("GS_WG_TARGET", 2 * kNumCU
 static int dyn_lds() { static const int v = env_int("GS_DYN_LDS", 0); return v; }
 static int min_ksteps() { static const int v = env_int("GS_MIN_KSTEPS", 4); return v; }
 
+extern int g_force_plan[3];  // capi_misc.hip: {bm, bn, splits} set by gs_debug_force_plan (0 = off)
+
 static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits = 64,
                       bool pipelined = true) {
   Plan pl{};
+  if (g_force_plan[0] > 0) {  // tuning sweeps (tools/sweep_conv_plans.py)
+    pl.bm = g_force_plan[0]; pl.bn = g_force_plan[1];
+    pl.tiles_m = (int)ceil_div(M, pl.bm); pl.tiles_n = (int)ceil_div(Nn, pl.bn);
+    pl.nk_total = (int)ceil_div(Ktot, BK);
+    int splits = std::max(1, std::min(g_force_plan[2], pl.nk_total));
+    if (!allow_split) splits = 1;
+    pl.nk_per_split = (int)ceil_div(pl.nk_total, splits);
+    pl.splits = (int)ceil_div(pl.nk_total, pl.nk_per_split);
+    return pl;
+  }
+  if (pipelined && !wg_target_forced() && env_int("GS_FORCE_BM", 0) == 0) {
+    // Row kernels (forward / dgrad), software-pipelined K loop.  Fitted to the r01 plan sweep
+    // (tools/sweep_conv_plans.py over the supernet's 1x1 / 3x3 shapes at 1024x512, bs 2;
+    // profiles/r01_plan_sweep.json): with the side work hidden behind the MFMAs a 64x64 tile runs
+    // as fast per FLOP as 128x128, and four times as many tiles mean far fewer (or no) split-K
+    // slabs to write and re-read -- s2 3x3 128: 63.8 -> 48.6 us, s4 3x3 640: 116 -> 72.6 us,
+    // s3 1x1 192->768: 33.4 -> 17.1 us.  Rule: 64-row tiles; the least padded column width of
+    // {80, 64, 48, 32} (larger on ties); split K only to reach ~2.5 workgroups per CU.
+    static const int kBNp[4] = {80, 64, 48, 32};
+    int best = 32, best_pad = 1 << 30;
+    for (int i = 0; i < 4; ++i) {
+      const int pad = (int)ceil_div(Nn, kBNp[i]) * kBNp[i];
+      if (pad < best_pad) { best_pad = pad; best = kBNp[i]; }
+    }
+    pl.bn = best;
+    pl.bm = 64;
+    pl.tiles_m = (int)ceil_div(M, pl.bm);
+    pl.tiles_n = (int)ceil_div(Nn, pl.bn);
+    pl.nk_total = (int)ceil_div(Ktot, BK);
+    const long tiles = (long)pl.tiles_m * pl.tiles_n;
+    const double want = 2.5 * kNumCU / (double)tiles;
+    int splits = 1;
+    if (allow_split && want > 1.0) {
+      const int lo = std::max(1, (int)want), hi = lo + 1;
+      splits = (want / lo <= hi / want) ? lo : hi;   // nearest in ratio
+      const int max_by_k = std::max(1, pl.nk_total / min_ksteps());
+      splits = std::min(splits, std::min(max_by_k, max_splits));
+      while (splits > 1 && (size_t)splits * M * Nn * sizeof(float) > kMaxSlabBytes) --splits;
+    }
+    pl.nk_per_split = (int)ceil_div(pl.nk_total, splits);
+    pl.splits = (int)ceil_div(pl.nk_total, pl.nk_per_split);
+    return pl;
+  }
   // BN: least padded width, larger tile on ties
   int best = 32, best_pad = 1 << 30;
   static const int bn_cap = env_int("GS_BN_CAP", 128);

@@ -289,6 +289,14 @@ int gs_confusion_matrix(const int64_t* pred, const int64_t* label, int64_t n, in
 int gs_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
                 float momentum, float weight_decay, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Tuning hook (tools/sweep_conv_plans.py): force tile rows (64|128), tile columns            */
+/* (32|48|64|80|96|128) and split-K factor of the following gs_conv2d_* calls; bm = 0 restores */
+/* the planner.  Process-global, not thread-safe, results stay exact (only the fixed summation */
+/* order of split-K changes).                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+int gs_debug_force_plan(int32_t bm, int32_t bn, int32_t splits);
+
 #ifdef __cplusplus
 }
 #endif
