@@ -367,6 +367,88 @@ __device__ __forceinline__ void rows_epilogue(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Software-pipelined K loop shared by the fast row and wgrad kernels.
+// One wave can run only ONE MFMA ahead of its instruction stream, so everything else a K step
+// needs (fragment reads of the next k-group, the gather's address math + global loads for step
+// i+3, the LDS stores of step i+1) is issued in the ~24 free issue cycles behind each 32-cycle MFMA
+// instead of in serial sections between MFMA bursts (r01 stamps of the sectioned loop: 2465 cycles
+// per K step for 1024 cycles of MFMA work per wave, MFMA pipe 75 % busy at 2 waves/SIMD).
+// sched_barrier(0) after every slot pins the hand-placed order.
+//   load_a(ra) / load_b(rb): issue the global loads of the NEXT unloaded K step (out-of-range
+//                            steps must load zeros: bounds-checked buffer loads), load_b advances;
+//   store_a(ra, As) / store_b(rb, Bs): registers -> k-major skewed LDS image.
+// Step i computes from buf[i&1]; two register sets hold steps i+1 and i+2 (in flight); the set
+// freed at step i is refilled with step i+3.  Unrolled by 6: buffer parity and set index static.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int AS, class LA, class LB, class SA, class SB>
+__device__ __forceinline__ void pipelined_k_loop(int nk, float* lds,
+                                                 f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN],
+                                                 int wave, int lane, LA&& load_a, LB&& load_b,
+                                                 SA&& store_a, SB&& store_b) {
+  using T = Tile<BM, BN>;
+  constexpr int NQ = T::TM * T::TN;            // MFMAs per k-group
+  const int kk = lane >> 4, li = lane & 15;
+  const int a_base = kk * T::PA + wave * T::WM + li;
+  const int b_base = T::A_SZ + kk * T::PB + li;
+  float fa[2][T::TM], fb[2][T::TN];
+  auto read_a = [&](const float* buf, int g, float (&a)[T::TM]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) a[i] = buf[a_base + g * (4 * T::PA + 8) + i * 16];
+  };
+  auto read_b = [&](const float* buf, int g, float (&b)[T::TN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) b[j] = buf[b_base + g * (4 * T::PB + 8) + j * 16];
+  };
+  // slots (index of the MFMA within its k-group) behind which the side work is issued
+  constexpr int Q_RB = NQ > 1 ? 1 : 0, Q_LA = NQ > 2 ? 2 : NQ - 1, Q_LB = NQ > 4 ? 4 : NQ - 1;
+  f32x4 ra0[AS], ra1[AS], ra2[AS];
+  f32x4 rb0[T::BV], rb1[T::BV], rb2[T::BV];
+  float* buf0 = lds;
+  float* buf1 = lds + T::STAGE;
+  auto phase = [&](f32x4 (&rla)[AS], f32x4 (&rlb)[T::BV], const f32x4 (&rsa)[AS],
+                   const f32x4 (&rsb)[T::BV], const float* bc, float* bn)
+                   __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int i = q / T::TN, j = q - i * T::TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+        if (g < 3 && q == 0) read_a(bc, g + 1, fa[nxt]);
+        if (g < 3 && q == Q_RB) read_b(bc, g + 1, fb[nxt]);
+        if (g == 0 && q == Q_LA) load_a(rla);
+        if (g == 0 && q == Q_LB) load_b(rlb);
+        if (g == 2 && q == Q_LA) store_a(rsa, bn);
+        if (g == 2 && q == Q_LB) store_b(rsb, bn + T::A_SZ);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    read_a(bn, 0, fa[0]);
+    read_b(bn, 0, fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (nk <= 0) return;
+  load_a(ra0); load_b(rb0);
+  load_a(ra1); load_b(rb1);
+  load_a(ra2); load_b(rb2);
+  store_a(ra0, buf0); store_b(rb0, buf0 + T::A_SZ);
+  __syncthreads();
+  read_a(buf0, 0, fa[0]);
+  read_b(buf0, 0, fb[0]);
+  for (int ib = 0; ib < nk; ib += 6) {
+    if (ib + 0 < nk) phase(ra0, rb0, ra1, rb1, buf0, buf1);
+    if (ib + 1 < nk) phase(ra1, rb1, ra2, rb2, buf1, buf0);
+    if (ib + 2 < nk) phase(ra2, rb2, ra0, rb0, buf0, buf1);
+    if (ib + 3 < nk) phase(ra0, rb0, ra1, rb1, buf1, buf0);
+    if (ib + 4 < nk) phase(ra1, rb1, ra2, rb2, buf0, buf1);
+    if (ib + 5 < nk) phase(ra2, rb2, ra0, rb0, buf1, buf0);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fast path of forward / stride-1 dgrad for the shapes that carry the FLOPs: NHWC source,
 // channels per tap a multiple of BK (every width of the search space is a multiple of 16), 1x1 or
@@ -533,29 +615,6 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
 #define GS_STAMP(x) if constexpr (ABL == 9) { x = gs_stamp(); }
   if constexpr (ABL == 9) st_k0 = __builtin_amdgcn_s_memrealtime();
   if constexpr (PIPE) {
-    // ---- software-pipelined K loop -------------------------------------------------------
-    // One wave can run only ONE MFMA ahead of its instruction stream, so everything else a K step
-    // needs (fragment reads of the next k-group, the gather's address math + global loads for
-    // step i+3, the LDS stores of step i+1) is issued in the ~24 free issue cycles behind each
-    // 32-cycle MFMA instead of in serial sections between MFMA bursts (r01 stamps: 2465 cycles
-    // per K step for 1024 cycles of MFMA work per wave; MFMA pipe 75 % busy at 2 waves/SIMD).
-    // sched_barrier(0) after every slot pins the hand-placed order.
-    constexpr int NQ = T::TM * T::TN;            // MFMAs per k-group
-    const int kk = lane >> 4, li = lane & 15;
-    const int a_base = kk * T::PA + wave * T::WM + li;
-    const int b_base = kk * T::PB + li;
-    float fa[2][T::TM], fb[2][T::TN];
-    auto read_a = [&](const float* buf, int g, float (&a)[T::TM]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < T::TM; ++i)
-        a[i] = (ABL >= 3 && ABL != 9) ? (float)(lane + i + g) : buf[a_base + g * (4 * T::PA + 8) + i * 16];
-    };
-    auto read_b = [&](const float* buf, int g, float (&b)[T::TN]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int j = 0; j < T::TN; ++j)
-        b[j] = (ABL >= 3 && ABL != 9) ? (float)(lane - j - g)
-                                      : buf[T::A_SZ + b_base + g * (4 * T::PB + 8) + j * 16];
-    };
     // scalar K-step state of the NEXT stage to load (no divisions in the loop)
     const int a_step_h = 4 * p.step_h * (int)p.s_h, a_step_w = 4 * p.step_w * (int)p.s_w;
     const int b_step_h = 4 * (int)p.d_tap_h, b_step_w = 4 * (int)p.d_tap_w;
@@ -624,50 +683,8 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
         }
       }
     };
-    // slots (index of the MFMA within its k-group) behind which the side work is issued
-    constexpr int Q_RB = NQ > 1 ? 1 : 0, Q_LA = NQ > 2 ? 2 : NQ - 1, Q_LB = NQ > 4 ? 4 : NQ - 1;
-    auto phase = [&](f32x4 (&rla)[AS], f32x4 (&rlb)[T::BV], const f32x4 (&rsa)[AS],
-                     const f32x4 (&rsb)[T::BV], const float* bc, float* bn)
-                     __attribute__((always_inline)) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cur = g & 1, nxt = cur ^ 1;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int i = q / T::TN, j = q - i * T::TN;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-          if (g < 3 && q == 0) read_a(bc, g + 1, fa[nxt]);
-          if (g < 3 && q == Q_RB) read_b(bc, g + 1, fb[nxt]);
-          if (g == 0 && q == Q_LA) load_a(rla);
-          if (g == 0 && q == Q_LB) load_b(rlb);
-          if (g == 2 && q == Q_LA) store_a(rsa, bn);
-          if (g == 2 && q == Q_LB) store_b(rsb, bn + T::A_SZ);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if constexpr (ABL < 4 || ABL == 9) __syncthreads();
-      read_a(bn, 0, fa[0]);
-      read_b(bn, 0, fb[0]);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    if (nk > 0) {
-      load_a(ra0); load_b(rb0);
-      load_a(ra1); load_b(rb1);
-      load_a(ra2); load_b(rb2);
-      store_a(ra0, buf0); store_b(rb0, buf0 + T::A_SZ);
-      __syncthreads();
-      read_a(buf0, 0, fa[0]);
-      read_b(buf0, 0, fb[0]);
-      GS_STAMP(st_l0)
-      for (int ib = 0; ib < nk; ib += 6) {
-        if (ib + 0 < nk) phase(ra0, rb0, ra1, rb1, buf0, buf1);
-        if (ib + 1 < nk) phase(ra1, rb1, ra2, rb2, buf1, buf0);
-        if (ib + 2 < nk) phase(ra2, rb2, ra0, rb0, buf0, buf1);
-        if (ib + 3 < nk) phase(ra0, rb0, ra1, rb1, buf1, buf0);
-        if (ib + 4 < nk) phase(ra1, rb1, ra2, rb2, buf0, buf1);
-        if (ib + 5 < nk) phase(ra2, rb2, ra0, rb0, buf1, buf0);
-      }
-    }
+    GS_STAMP(st_l0)
+    pipelined_k_loop<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
   } else {
   // step i computes from buf[i&1]; two register sets hold steps i+1 and i+2 (in flight); the set
   // freed at step i is refilled with step i+3.  Unrolled by 6: buffer parity and set index static.
@@ -936,75 +953,59 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
 #pragma unroll
     for (int b = 0; b < T::TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto load = [&](f32x4 (&ra)[AS], f32x4 (&rb)[T::BV]) {
+  // advancing a slot by BK pixels in the (n, h, w) mixed radix, branch-free (one carry per digit)
+  const int adv_w = BK % p.Wp, adv_q = BK / p.Wp;
+  const int adv_h = adv_q % p.Hp, adv_n = adv_q / p.Hp;
+  int k_left = nk;
+  auto load_a = [&](f32x4 (&ra)[AS]) __attribute__((always_inline)) {
+    const bool kvalid = k_left > 0;
 #pragma unroll
     for (int s = 0; s < AS; ++s) {
       const int hi = ph[s] * p.mul_h + offh, wi = pw[s] * p.mul_w + offw;
-      const bool ok = iv && pn[s] < Nb && (unsigned)hi < (unsigned)p.Hs && (unsigned)wi < (unsigned)p.Ws;
+      const bool ok = kvalid && iv && pn[s] < Nb && (unsigned)hi < (unsigned)p.Hs &&
+                      (unsigned)wi < (unsigned)p.Ws;
       const unsigned off =
           ok ? 4u * (unsigned)(pn[s] * (int)p.s_n + hi * (int)p.s_h + wi * (int)p.s_w + c) : kOOB;
       ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
-      // advance this slot by BK pixels
-      pw[s] += BK;
-      while (pw[s] >= p.Wp) { pw[s] -= p.Wp; ++ph[s]; }
-      while (ph[s] >= p.Hp) { ph[s] -= p.Hp; ++pn[s]; }
+      const int w2 = pw[s] + adv_w;
+      const int cw = w2 >= p.Wp ? 1 : 0;
+      pw[s] = w2 - (cw ? p.Wp : 0);
+      const int h2 = ph[s] + adv_h + cw;
+      const int ch = h2 >= p.Hp ? 1 : 0;
+      ph[s] = h2 - (ch ? p.Hp : 0);
+      pn[s] += adv_n + ch;
     }
+  };
+  auto load_b = [&](f32x4 (&rb)[T::BV]) __attribute__((always_inline)) {
+    const bool kvalid = k_left > 0;
 #pragma unroll
     for (int r = 0; r < T::BV; ++r) {
       const int m = kt_load * BK + brow[r];
-      const unsigned off = (bok[r] && m < p.npix) ? 4u * (unsigned)(m * p.d_row + bcol[r]) : kOOB;
+      const unsigned off =
+          (kvalid && bok[r] && m < p.npix) ? 4u * (unsigned)(m * p.d_row + bcol[r]) : kOOB;
       rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dense, off, 0, 0));
     }
     ++kt_load;
+    --k_left;
   };
-
-  auto store = [&](const f32x4 (&ra)[AS], const f32x4 (&rb)[T::BV], float* buf) {
-    float* As = buf;
-    float* Bs = buf + T::A_SZ;
+  auto store_a = [&](const f32x4 (&ra)[AS], float* As) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < AS; ++s) {
       const int kr = krA + s * KSTR;
       *reinterpret_cast<f32x4*>(&As[kr * T::PA + 8 * (kr >> 2) + iq * 4]) = ra[s];
     }
+  };
+  auto store_b = [&](const f32x4 (&rb)[T::BV], float* Bs) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < T::BV; ++r) {
       const int idx = t + NT * r;
-      if (idx < BK * BN / 4) {
+      if ((r + 1) * NT <= BK * BN / 4 || idx < BK * BN / 4) {
         const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
         *reinterpret_cast<f32x4*>(&Bs[kr * T::PB + 8 * (kr >> 2) + nq * 4]) = rb[r];
       }
     }
   };
-
-  f32x4 ra0[AS], ra1[AS], ra2[AS];
-  f32x4 rb0[T::BV], rb1[T::BV], rb2[T::BV];
-  float* buf0 = lds;
-  float* buf1 = lds + T::STAGE;
-  // step i computes from buf[i&1]; sets hold steps i+1, i+2; the set freed at step i is
-  // refilled with step i+3.  Unrolled by 6 so that buffer parity and set index are static.
-#define GS_WG_PHASE(I, RL_A, RL_B, RS_A, RS_B, BC, BN_)                          \
-  if ((I) < nk) {                                                               \
-    if ((I) + 3 < nk) load(RL_A, RL_B);                                         \
-    mfma_stage<BM, BN>(BC, BC + T::A_SZ, acc, wave, lane);                      \
-    if ((I) + 1 < nk) store(RS_A, RS_B, BN_);                                   \
-    __syncthreads();                                                            \
-  }
-  if (nk > 0) {
-    load(ra0, rb0);
-    if (nk > 1) load(ra1, rb1);
-    if (nk > 2) load(ra2, rb2);
-    store(ra0, rb0, buf0);
-    __syncthreads();
-    for (int ib = 0; ib < nk; ib += 6) {
-      GS_WG_PHASE(ib + 0, ra0, rb0, ra1, rb1, buf0, buf1)
-      GS_WG_PHASE(ib + 1, ra1, rb1, ra2, rb2, buf1, buf0)
-      GS_WG_PHASE(ib + 2, ra2, rb2, ra0, rb0, buf0, buf1)
-      GS_WG_PHASE(ib + 3, ra0, rb0, ra1, rb1, buf1, buf0)
-      GS_WG_PHASE(ib + 4, ra1, rb1, ra2, rb2, buf0, buf1)
-      GS_WG_PHASE(ib + 5, ra2, rb2, ra0, rb0, buf1, buf0)
-    }
-  }
-#undef GS_WG_PHASE
+  pipelined_k_loop<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
 
   float* Cs = lds;
   constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
@@ -1103,7 +1104,7 @@ static int min_ksteps() { static const int v = env_int("GS_MIN_KSTEPS", 4); retu
 extern int g_force_plan[3];  // capi_misc.hip: {bm, bn, splits} set by gs_debug_force_plan (0 = off)
 
 static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits = 64,
-                      bool pipelined = true) {
+                      bool pipelined = true, double wg_per_cu = 2.5) {
   Plan pl{};
   if (g_force_plan[0] > 0) {  // tuning sweeps (tools/sweep_conv_plans.py)
     pl.bm = g_force_plan[0]; pl.bn = g_force_plan[1];
@@ -1122,7 +1123,8 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
     // as fast per FLOP as 128x128, and four times as many tiles mean far fewer (or no) split-K
     // slabs to write and re-read -- s2 3x3 128: 63.8 -> 48.6 us, s4 3x3 640: 116 -> 72.6 us,
     // s3 1x1 192->768: 33.4 -> 17.1 us.  Rule: 64-row tiles; the least padded column width of
-    // {80, 64, 48, 32} (larger on ties); split K only to reach ~2.5 workgroups per CU.
+    // {80, 64, 48, 32} (larger on ties); split K only to reach ~2.5 workgroups per CU (row
+    // kernels) or ~4 per CU (wgrad, whose K = pixels is long and whose outputs are small).
     static const int kBNp[4] = {80, 64, 48, 32};
     int best = 32, best_pad = 1 << 30;
     for (int i = 0; i < 4; ++i) {
@@ -1135,7 +1137,7 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
     pl.tiles_n = (int)ceil_div(Nn, pl.bn);
     pl.nk_total = (int)ceil_div(Ktot, BK);
     const long tiles = (long)pl.tiles_m * pl.tiles_n;
-    const double want = 2.5 * kNumCU / (double)tiles;
+    const double want = wg_per_cu * kNumCU / (double)tiles;
     int splits = 1;
     if (allow_split && want > 1.0) {
       const int lo = std::max(1, (int)want), hi = lo + 1;
@@ -1281,7 +1283,9 @@ static Plan plan_dgrad(const gs_conv_desc* d) {
 }
 static Plan plan_wgrad(const gs_conv_desc* d) {
   // wgrad: K runs over pixels (up to 131072 at stage 1) while M x N is tiny: allow deep split-K
-  return make_plan(d->KH * d->KW * d->Ci, d->Co, d->N * d->Ho * d->Wo, true, 512, false);
+  static const int old_plan = env_int("GS_WGRAD_OLD_PLAN", 0);
+  if (old_plan) return make_plan(d->KH * d->KW * d->Ci, d->Co, d->N * d->Ho * d->Wo, true, 512, false);
+  return make_plan(d->KH * d->KW * d->Ci, d->Co, d->N * d->Ho * d->Wo, true, 512, true, 4.0);
 }
 static size_t slab_bytes(const Plan& pl, long M, int Nn) {
   return pl.splits > 1 ? (size_t)pl.splits * M * Nn * sizeof(float) : 0;
