@@ -183,6 +183,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.train_iter(next(loader))
+    host_issue = time.perf_counter() - t0   # host time to enqueue the steps (diagnostic only)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -217,6 +218,7 @@ def main():
                 "global_batch": world * bs,
                 "parallelism": "dp%d" % world,
                 "last_loss": round(loss, 5),
+                "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
             },
         }
         hooks = [h for h in runner.hooks if isinstance(h, ManipulateArchHook)]

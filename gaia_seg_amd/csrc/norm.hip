@@ -79,9 +79,11 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
   block_reduce_rows(s1, s2, m, C4, sh);
   if (m.active && m.rr == 0) {
-    float* o = part + (long)blockIdx.x * 2 * C;
-    *reinterpret_cast<f32x4*>(o + m.cq * 4) = s1;
-    *reinterpret_cast<f32x4*>(o + C + m.cq * 4) = s2;
+    // quad-major partial layout (element (p, Q) at part4[Q * nparts + p]): the summing kernels
+    // then read every quad's partials as one contiguous run
+    f32x4* part4 = reinterpret_cast<f32x4*>(part);
+    part4[(long)m.cq * gridDim.x + blockIdx.x] = s1;
+    part4[((long)C4 + m.cq) * gridDim.x + blockIdx.x] = s2;
   }
 }
 
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 // 16 dependent-latency iterations, 12 us; this form is launch-latency bound.)
 template <int NV>
 __device__ __forceinline__ void block_sum_quads(const float* __restrict__ part, int nparts,
-                                                long stride, const int (&col)[NV],
+                                                const int (&col)[NV] /* quad indices */,
                                                 double (&a)[4 * NV], double* sh /* [4][4*NV] */) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #pragma unroll
@@ -105,7 +107,7 @@ __device__ __forceinline__ void block_sum_quads(const float* __restrict__ part, 
       const int p = base + u * 256 + t;
 #pragma unroll
       for (int j = 0; j < NV; ++j)
-        v[u][j] = p < nparts ? *reinterpret_cast<const f32x4*>(part + (long)p * stride + col[j])
+        v[u][j] = p < nparts ? reinterpret_cast<const f32x4*>(part)[(long)col[j] * nparts + p]
                              : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -142,9 +144,9 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   }
   const int q = blockIdx.x;
   if (q * 4 >= width) return;   // block-uniform
-  const int col[1] = {q * 4};
+  const int col[1] = {q};
   double a[4];
-  block_sum_quads<1>(part, nparts, width, col, a, sh);
+  block_sum_quads<1>(part, nparts, col, a, sh);
   if (threadIdx.x == 0)
     *reinterpret_cast<f32x4*>(out + q * 4) = f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
 }
@@ -166,9 +168,9 @@ __global__ __launch_bounds__(256) void bn_sum_finalize_kernel(
     float* running_mean, float* running_var, float* __restrict__ coeffs) {
   __shared__ double sh[32];
   const int q = blockIdx.x;
-  const int col[2] = {q * 4, C + q * 4};
+  const int col[2] = {q, C / 4 + q};
   double a[8];
-  block_sum_quads<2>(part, nparts, 2L * C, col, a, sh);
+  block_sum_quads<2>(part, nparts, col, a, sh);
   const int lane = threadIdx.x;
   if (lane < 4) {
     const int c = q * 4 + lane;
@@ -307,9 +309,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(
   }
   block_reduce_rows(s1, s2, m, C4, sh);
   if (m.active && m.rr == 0) {
-    float* o = part + (long)blockIdx.x * 2 * C;
-    *reinterpret_cast<f32x4*>(o + m.cq * 4) = s1;
-    *reinterpret_cast<f32x4*>(o + C + m.cq * 4) = s2;
+    // quad-major partial layout (element (p, Q) at part4[Q * nparts + p]): the summing kernels
+    // then read every quad's partials as one contiguous run
+    f32x4* part4 = reinterpret_cast<f32x4*>(part);
+    part4[(long)m.cq * gridDim.x + blockIdx.x] = s1;
+    part4[((long)C4 + m.cq) * gridDim.x + blockIdx.x] = s2;
   }
 }
 
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
   block_reduce_rows(s1, s2, m, C4, sh);
   if (m.active && m.rr == 0)
-    *reinterpret_cast<f32x4*>(part + (long)blockIdx.x * C + m.cq * 4) = s1;
+    reinterpret_cast<f32x4*>(part)[(long)m.cq * gridDim.x + blockIdx.x] = s1;
 }
 
 // ---- host helpers ----
@@ -378,8 +382,10 @@ static RedGeom red_geom(long rows, int C) {
   g.gy = C4 <= 256 ? 1 : (int)ceil_div(C4, 256);
   const int rpi = C4 <= 256 ? 256 / C4 : 1;
   // ~4 iterations per block at least, at most 1024 row blocks (partials stay small)
-  long gx = ceil_div(rows, (long)rpi * 4);
-  const long cap = std::max<long>(1, 1024 / g.gy);
+  static const int it_min = getenv("GS_BNORM_ITERS") ? atoi(getenv("GS_BNORM_ITERS")) : 4;
+  static const int gx_cap = getenv("GS_BNORM_PARTS") ? atoi(getenv("GS_BNORM_PARTS")) : 1024;
+  long gx = ceil_div(rows, (long)rpi * it_min);
+  const long cap = std::max<long>(1, gx_cap / g.gy);
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   g.rows_per_block = ceil_div(rows, gx);
