@@ -126,6 +126,9 @@ class GradReducer:
         st["launched"][bi] = True
         if world_size() == 1:
             return
+        if self.flat_grad.is_cuda:
+            from ..hip import ops as _ops
+            _ops.join_side_streams(self.flat_grad.device)  # wgrads of this bucket run on a side stream
         for a, b in st["plan"][bi]["runs"]:
             t = self.flat_grad[a:b]
             self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group,

@@ -57,6 +57,8 @@ struct IgemmArgs {
   // output row lattice: row m = (n, hq, wq) -> pixel (n, hq*o_s + o_ph, wq*o_s + o_pw) of an
   // o_H x o_W image (o_s == 0: rows are dense pixels)
   int o_s, o_ph, o_pw, o_Hq, o_Wq, o_H, o_W;
+  // fast kernels: 1-D grid of tiles x splits, split-major; tile_order 1 = tm fastest
+  int nsplits, tile_order;
 };
 
 // pixel index of GEMM row m in the output tensor
@@ -153,7 +155,8 @@ __global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kt0 = blockIdx.y * p.nk_per_split;
+  const int split = blockIdx.y;
+  const int kt0 = split * p.nk_per_split;
   const int kt1 = min(kt0 + p.nk_per_split, p.nk_total);
 
   // per-thread row geometry (constant over the K loop)
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
 template <int BM, int BN>
 __device__ __forceinline__ void rows_epilogue(
     const IgemmArgs& p, float* lds, const f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN], int m0,
-    int n0, int t, int wave, int lane) {
+    int n0, int t, int wave, int lane, int split) {
   using T = Tile<BM, BN>;
   float* Cs = lds;
   constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
@@ -354,7 +357,7 @@ __device__ __forceinline__ void rows_epilogue(
       if (ch * T::CCH + q * 4 < BN && m < p.M && col < p.Nn) {
         f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * T::PC + q * 4]);
         if (p.slab) {
-          *reinterpret_cast<f32x4*>(p.slab + ((long)blockIdx.y * p.M + m) * p.Nn + col) = v;
+          *reinterpret_cast<f32x4*>(p.slab + ((long)split * p.M + m) * p.Nn + col) = v;
         } else {
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
           if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (long)m * p.ld_add + col);
@@ -480,11 +483,18 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
   const int ntaps = p.kh_n * p.kw_n;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // 1-D grid over (split, tile), split-major, remapped so that every XCD owns one contiguous run:
+  // the tiles that share an operand sit behind the same L2.  tile_order 1 walks tm fastest (the
+  // dense operand is the larger one: each XCD then needs only a few of its column blocks).
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int lin = xcd_remap(blockIdx.x, ntiles * p.nsplits);
+  const int split = lin / ntiles;
+  const int tile = lin - split * ntiles;
+  int tm, tn;
+  if (p.tile_order) { tn = tile / p.tiles_m; tm = tile - tn * p.tiles_m; }
+  else { tm = tile / p.tiles_n; tn = tile - tm * p.tiles_n; }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kt0 = blockIdx.y * p.nk_per_split;
+  const int kt0 = split * p.nk_per_split;
   const int kt1 = min(kt0 + p.nk_per_split, p.nk_total);
   const int nk = kt1 - kt0;
 
@@ -726,7 +736,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     float* keep = p.slab;
     IgemmArgs q = p;
     q.slab = nullptr;
-    rows_epilogue<BM, BN>(q, lds, acc, m0, n0, t, wave, lane);
+    rows_epilogue<BM, BN>(q, lds, acc, m0, n0, t, wave, lane, split);
     const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
       unsigned long long* o = reinterpret_cast<unsigned long long*>(keep) + ((long)blockIdx.x * 4 + wave) * 8;
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
       o[4] = d_load; o[5] = d_mfma; o[6] = d_store; o[7] = d_bar;
     }
   } else {
-    rows_epilogue<BM, BN>(p, lds, acc, m0, n0, t, wave, lane);
+    rows_epilogue<BM, BN>(p, lds, acc, m0, n0, t, wave, lane, split);
   }
 #undef GS_STAMP
 }
@@ -899,11 +909,15 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
   constexpr int KSTR = NT / QA;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // 1-D grid over (split, tile), split-major + XCD remap: all tiles of one pixel range (they gather
+  // the same x region and read the same dy rows) sit behind the same L2
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int lin = xcd_remap(blockIdx.x, ntiles * p.nsplits);
+  const int split = lin / ntiles;
+  const int tile = lin - split * ntiles;
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int i0 = tm * BM, n0 = tn * BN;
-  const int kt0 = blockIdx.y * p.nk_per_split;
+  const int kt0 = split * p.nk_per_split;
   const int kt1 = min(kt0 + p.nk_per_split, p.nk_total);
   const int nk = kt1 - kt0;
 
@@ -1022,7 +1036,7 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
       if (ch * T::CCH + q * 4 < BN && ir < p.M && col < p.Nn) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * T::PC + q * 4]);
         if (p.slab) {
-          *reinterpret_cast<f32x4*>(p.slab + ((long)blockIdx.y * p.M + ir) * p.Nn + col) = v;
+          *reinterpret_cast<f32x4*>(p.slab + ((long)split * p.M + ir) * p.Nn + col) = v;
         } else {
           const int tp = ir / p.Cs, cc = ir - tp * p.Cs;
           *reinterpret_cast<f32x4*>(p.out + (long)tp * p.o_tap + (long)cc * p.o_row + col) = v;
@@ -1212,8 +1226,15 @@ static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
 }
 
 template <bool BTRANS, int KS, int ROLE = 0>
-static void launch_rows_fast(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
-  const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
+static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t st) {
+  IgemmArgs a = a_in;
+  a.nsplits = pl.splits;
+  {  // the larger operand should cross the fabric once: see the kernel's tile decode
+    const double a_bytes = 4.0 * a.npix * a.Cs, b_bytes = 4.0 * a.taps * a.Cs * a.Nn;
+    static const int force = env_int("GS_TILE_ORDER", -1);
+    a.tile_order = force >= 0 ? force : (b_bytes > a_bytes ? 1 : 0);
+  }
+  const dim3 grid(pl.tiles_m * pl.tiles_n * pl.splits), block(NT);
 #define GS_FAST(BM_, BN_)                                                                  \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                      \
     hipLaunchKernelGGL((igemm_rows_fast_kernel<BM_, BN_, BTRANS, KS, 0, ROLE>), grid, block, dyn_lds(), st, a); \
@@ -1231,8 +1252,10 @@ static inline bool fast_rows_ok(int cs, int ks, size_t src_bytes, size_t dense_b
 }
 
 template <int KS>
-static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
-  const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
+static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t st) {
+  IgemmArgs a = a_in;
+  a.nsplits = pl.splits;
+  const dim3 grid(pl.tiles_m * pl.tiles_n * pl.splits), block(NT);
 #define GS_WGF(BM_, BN_)                                                                  \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                     \
     hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS>), grid, block, dyn_lds(), st, a);   \

@@ -8,10 +8,41 @@ import ctypes
 
 import torch
 
+import os
+
 from . import lib as _lib
-from .runtime import WORKSPACE, Act, current_stream_ptr, round_up
+from .runtime import WORKSPACE, Act, _Workspace, current_stream_ptr, round_up
 
 _ws = WORKSPACE
+
+# ---- weight gradients on a side stream -------------------------------------------------------
+# In backward the weight gradient of a conv is needed only by the optimizer (and the gradient
+# all-reduce), while the data gradient is on the critical path.  The wgrad kernels (MFMA-bound) are
+# therefore launched on a second HIP stream, fenced by events, and run concurrently with the
+# BN-backward / dgrad kernels of the following layers (HBM-bound) on the main stream.  The main
+# stream joins the side stream at the end of every tape backward and before a gradient bucket is
+# handed to RCCL.  GS_SIDE_WGRAD=0 keeps everything on one stream.
+SIDE_WGRAD = os.environ.get("GS_SIDE_WGRAD", "1") != "0"
+_side_streams = {}
+_side_dirty = {}
+_ws_side = _Workspace()
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    s = _side_streams.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _side_streams[key] = s
+    return s
+
+
+def join_side_streams(dev=None):
+    """Make the current stream wait for the weight-gradient kernels queued on the side stream."""
+    for key, s in _side_streams.items():
+        if _side_dirty.get(key) and (dev is None or (dev.type, dev.index) == key):
+            torch.cuda.current_stream(s.device).wait_stream(s)
+            _side_dirty[key] = False
 
 
 def _L():
@@ -136,8 +167,20 @@ def conv2d(tape, x, weight, bias, co, stride=1, pad=0, dil=1, out=None, tag=None
         s = current_stream_ptr()
         if weight.requires_grad:
             gw = ensure_grad(weight)
-            _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
-                                         ws_b.data_ptr(), ws_b.numel(), s), "gs_conv2d_wgrad")
+            if SIDE_WGRAD:
+                side = _side_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))   # dy (and gw's zeroing) ready
+                with torch.cuda.stream(side):
+                    ws_s = _ws_side.get(need, dev)
+                dy.record_stream(side)
+                x.t.record_stream(side)
+                _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
+                                             ws_s.data_ptr(), ws_s.numel(), side.cuda_stream),
+                           "gs_conv2d_wgrad")
+                _side_dirty[(dev.type, dev.index)] = True
+            else:
+                _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
+                                             ws_b.data_ptr(), ws_b.numel(), s), "gs_conv2d_wgrad")
             _notify(weight)
         if bias is not None and bias.requires_grad:
             gb = ensure_grad(bias)

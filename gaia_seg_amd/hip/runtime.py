@@ -204,6 +204,8 @@ class Tape:
         self.ops = []
         for fn in reversed(ops):
             fn()
+        from . import ops as _ops
+        _ops.join_side_streams()   # weight gradients queued on the side stream
 
 
 class _TapeFunction(torch.autograd.Function):
