@@ -44,6 +44,10 @@ def parse_args():
     ap.add_argument("--cpu-baseline-size", default="512x1024",
                     help="HxW of the bounded CPU sample (bs 1, R50 anchor)")
     ap.add_argument("--no-k3-timer", action="store_true")
+    ap.add_argument("--crop", default=None,
+                    help="HxW override of the crop size (diagnostics only, e.g. 64x128 makes the GPU "
+                         "work negligible and exposes the host cost per step; the headline "
+                         "number is always the config's 512x1024)")
     return ap.parse_args()
 
 
@@ -166,35 +170,59 @@ def main():
 
     bs = cfg.data["samples_per_gpu"]
     size = tuple(cfg.crop_size)
+    if args.crop:
+        size = tuple(int(v) for v in args.crop.split("x"))
     loader = SyntheticLoader(bs, size, num_classes=19, seed=args.seed, rank=rank, device=dev)
 
     for _ in range(args.warmup):
         runner.train_iter(next(loader))
     torch.cuda.synchronize()
 
+    if runner.host_prof is not None:
+        runner.host_prof.clear()
     timer = None
     if not args.no_k3_timer:
-        timer = ops.KernelTimer()
-        ops.TIMER = timer
+        # HIP events on the launch stream around every bottleneck-conv2 forward (conv + its split-K
+        # reduce), recorded inside the library (gs_k3_timer_*, include/gaiaseg_hip.h)
+        timer = lib.load()
+        lib.check(timer.gs_k3_timer_enable(1), "gs_k3_timer_enable")
     arch_log_start = runner.iter
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    prof = None
+    if os.environ.get("GS_CPROFILE"):   # diagnostics: host profile of the timed loop (main thread)
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.train_iter(next(loader))
-    host_issue = time.perf_counter() - t0   # host time to enqueue the steps (diagnostic only)
+    if prof is not None:
+        prof.disable()
+        import pstats
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(40)
+        from gaia_seg_amd.hip import runtime as _rt
+        if _rt.BACKWARD_PROFILE is not None:
+            print("---- backward thread ----", file=sys.stderr)
+            pstats.Stats(_rt.BACKWARD_PROFILE, stream=sys.stderr).sort_stats("tottime").print_stats(30)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    ops.TIMER = None
+    if timer is not None:
+        lib.check(timer.gs_k3_timer_enable(0), "gs_k3_timer_enable")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    loss = float(runner.outputs["loss"])
+    if runner.host_prof:
+        hp = runner.host_prof
+        n = max(hp.pop("iters", 1), 1)
+        print("host ms/iter: " + ", ".join("%s %.2f" % (k, 1e3 * v / n) for k, v in hp.items()),
+              file=sys.stderr)
+    loss = float(runner.outputs["loss"].detach())
     if rank == 0:
         imgs = world * bs * args.steps
         out = {
@@ -218,16 +246,18 @@ def main():
                 "global_batch": world * bs,
                 "parallelism": "dp%d" % world,
                 "last_loss": round(loss, 5),
-                "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
             },
         }
         hooks = [h for h in runner.hooks if isinstance(h, ManipulateArchHook)]
         if hooks:
             out["config"]["archs"] = hooks[0].history[arch_log_start:]
         if timer is not None:
-            summ = timer.summary().get("k3.fwd")
-            if summ:
-                launches, ms, flops = summ
+            import ctypes
+            c_n, c_ms, c_fl = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+            lib.check(timer.gs_k3_timer_read(ctypes.byref(c_n), ctypes.byref(c_ms), ctypes.byref(c_fl)),
+                      "gs_k3_timer_read")
+            if c_n.value:
+                launches, ms, flops = c_n.value, c_ms.value, c_fl.value
                 achieved = flops / (ms * 1e-3) / 1e12
                 out["roofline"] = {
                     "kernel": "igemm_rows_fast_kernel<BM,BN,false,3,0,1> + splitk_reduce_kernel<false,1> (dynamic 3x3 bottleneck conv "

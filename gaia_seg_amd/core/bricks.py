@@ -17,6 +17,8 @@ physical layout is HWIO so the kernels read the active leading slice in place.
 import math
 import warnings
 
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
@@ -333,6 +335,24 @@ def build_activation_layer(cfg):
     return build_from_cfg(cfg, ACTIVATION_LAYERS)
 
 
+def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=None):
+    """conv -> norm (+ residual) (+ ReLU).  Rank-local BatchNorm after a bias-free conv goes through
+    the one-call-per-direction library entry (ops.conv_bn); SyncBN with a process group, a conv
+    bias, widths that are not multiples of 4 and subnet extraction take the module-by-module path.
+    Both paths launch the same kernels."""
+    c = conv.width_state
+    fused = (conv.bias is None and c % 4 == 0 and not getattr(conv, "_deploying", False)
+             and not getattr(norm, "_deploying", False) and os.environ.get("GS_NO_FUSED_CALLS") is None)
+    if fused:
+        bnp = norm.bn_params(c)
+        if bnp.process_group is None:
+            conv._check_layout()
+            return ops.conv_bn(tape, x, conv.weight, c, bnp, conv.stride, conv.padding,
+                               conv.dilation, relu=relu, residual=residual, out=out, tag=tag)
+    y = conv.forward_act(tape, x, tag=tag)
+    return norm.forward_act(tape, y, relu=relu, residual=residual, out=out)
+
+
 # ------------------------------------------------------------------------------------------
 # DynamicConvModule  (mmcv ConvModule with dynamic conv / norm)
 # ------------------------------------------------------------------------------------------
@@ -385,8 +405,7 @@ class DynamicConvModule(nn.Module, DynamicMixin):
     def forward_act(self, tape, x, activate=True, norm=True, out=None):
         relu = bool(activate) and self.with_activation
         if norm and self.with_norm:
-            y = self.conv.forward_act(tape, x)
-            return self.norm.forward_act(tape, y, relu=relu, out=out)
+            return conv_bn_act(tape, self.conv, self.norm, x, relu=relu, out=out)
         if relu:
             raise NotImplementedError("ReLU without norm is not used on the hot path")
         return self.conv.forward_act(tape, x, out=out)
@@ -466,20 +485,22 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
         # stride-2 1x1 conv that have no tap then need no zero fill at all
         identity = x
         if self.downsample is not None:
-            for m in self.downsample:
-                if isinstance(m, DynamicConv2d):
-                    identity = m.forward_act(tape, identity)
-                elif isinstance(m, DynamicBatchNorm2d):
-                    identity = m.forward_act(tape, identity, relu=False)
-                else:
-                    raise NotImplementedError(
-                        "downsample member %s (avg_down) has no HIP kernel yet" % type(m).__name__)
-        out = self.conv1.forward_act(tape, x)
-        out = self.norm1.forward_act(tape, out, relu=True)
-        out = self.conv2.forward_act(tape, out, tag="k3")  # the roofline kernel
-        out = self.norm2.forward_act(tape, out, relu=True)
-        out = self.conv3.forward_act(tape, out)
-        return self.norm3.forward_act(tape, out, relu=True, residual=identity)
+            members = list(self.downsample)
+            if (len(members) == 2 and isinstance(members[0], DynamicConv2d)
+                    and isinstance(members[1], DynamicBatchNorm2d)):
+                identity = conv_bn_act(tape, members[0], members[1], x, relu=False)
+            else:
+                for m in members:
+                    if isinstance(m, DynamicConv2d):
+                        identity = m.forward_act(tape, identity)
+                    elif isinstance(m, DynamicBatchNorm2d):
+                        identity = m.forward_act(tape, identity, relu=False)
+                    else:
+                        raise NotImplementedError("downsample member %s (avg_down) has no HIP "
+                                                  "kernel yet" % type(m).__name__)
+        out = conv_bn_act(tape, self.conv1, self.norm1, x, relu=True)
+        out = conv_bn_act(tape, self.conv2, self.norm2, out, relu=True, tag="k3")
+        return conv_bn_act(tape, self.conv3, self.norm3, out, relu=True, residual=identity)
 
     def forward(self, x):
         needs = any(p.requires_grad for p in self.parameters())

@@ -81,10 +81,16 @@ class ArenaOptimizerHook(Hook):
             raise NotImplementedError("grad_clip is not configured by the in-tree configs")
 
     def after_train_iter(self, runner):
+        prof = runner.host_prof
+        t0 = time.perf_counter() if prof is not None else 0.0
         runner.outputs["loss"].backward()
+        t1 = time.perf_counter() if prof is not None else 0.0
         runner.reducer.finish()
         runner.arena.sgd_step(runner.active_ranges, runner.lr, runner.momentum, runner.weight_decay,
                               1.0 / gdist.world_size())
+        if prof is not None:
+            prof["backward"] = prof.get("backward", 0.0) + (t1 - t0)
+            prof["finish+sgd"] = prof.get("finish+sgd", 0.0) + (time.perf_counter() - t1)
 
 
 class TextLoggerHook(Hook):
@@ -139,6 +145,8 @@ class IterBasedRunner:
         self.active_params = None
         self.active_ranges = None
         self.arch_key = None
+        # GS_HOST_PROF=1: accumulate host-side seconds per phase of train_iter (diagnostics)
+        self.host_prof = {} if os.environ.get("GS_HOST_PROF") else None
         self.set_arch(None)
 
     def register_hook(self, hook):
@@ -164,12 +172,24 @@ class IterBasedRunner:
         self.active_ranges = self.arena.ranges_for(self.active_params, self.arch_key)
 
     def train_iter(self, data_batch):
-        self.model.train()
+        prof = self.host_prof
+        t0 = time.perf_counter() if prof is not None else 0.0
+        if not self.model.training:   # (a full module walk: ~1.5 ms of host time per call)
+            self.model.train()
         self.call_hook("before_train_iter")
+        t1 = time.perf_counter() if prof is not None else 0.0
         self.arena.zero_grad(self.active_ranges)
         self.reducer.begin(self.active_params, self.arch_key)
+        t2 = time.perf_counter() if prof is not None else 0.0
         self.outputs = self.model.train_step(data_batch, None)
+        t3 = time.perf_counter() if prof is not None else 0.0
         self.call_hook("after_train_iter")
+        if prof is not None:
+            t4 = time.perf_counter()
+            for k, v in (("hooks_before", t1 - t0), ("zero+begin", t2 - t1), ("forward", t3 - t2),
+                         ("backward+opt", t4 - t3)):
+                prof[k] = prof.get(k, 0.0) + v
+            prof["iters"] = prof.get("iters", 0) + 1
         self.iter += 1
         return self.outputs
 

@@ -29,3 +29,23 @@ extern "C" int gs_debug_force_plan(int bm, int bn, int splits) {
   gs::g_force_plan[0] = bm; gs::g_force_plan[1] = bn; gs::g_force_plan[2] = splits;
   return GS_OK;
 }
+
+// Stream fork / join without per-call event objects on the host side: work enqueued on `to` after
+// this call starts only once everything enqueued on `from` before it has finished.  (hip events
+// are re-recordable; hipStreamWaitEvent snapshots the record it sees, so a small ring suffices.)
+extern "C" int gs_stream_fork(void* from, void* to) {
+  constexpr int kRing = 256;
+  static thread_local hipEvent_t ring[kRing];
+  static thread_local int next = 0, made = 0;
+  if (made < kRing && next == made) {
+    hipError_t e = hipEventCreateWithFlags(&ring[made], hipEventDisableTiming);
+    if (e != hipSuccess) return static_cast<int>(e);
+    ++made;
+  }
+  hipEvent_t ev = ring[next];
+  next = (next + 1) % kRing;
+  hipError_t e = hipEventRecord(ev, gs::as_stream(from));
+  if (e != hipSuccess) return static_cast<int>(e);
+  e = hipStreamWaitEvent(gs::as_stream(to), ev, 0);
+  return e == hipSuccess ? GS_OK : static_cast<int>(e);
+}

@@ -1,0 +1,135 @@
+// conv -> BatchNorm (+ residual) (+ ReLU) as ONE host call per direction, and the live K3 timer.
+//
+// The reference runs DynConv2d, DynBN and ReLU as three Python-level modules
+// (gaiavision DynamicConvModule; DynamicBottleneck.forward at the call site
+// gaiaseg/models/utils/dynamic_res_layer.py:84-125).  Every launch of this path is a few tens of
+// microseconds of work on an MI355X, so the per-module host cost of an eager framework (~35 us)
+// is of the same order as the kernels themselves: with one host call per module the host, not
+// the GPU, sets the step time for the deeper subnets.  These entry points issue the launches of a
+// conv+BN pair back to back from C (forward: conv, [split-K reduce], BN statistics, finalize,
+// apply; backward: BN reduce, BN apply, wgrad on the side stream, dgrad).  They only compose the
+// operator entry points of this library: results are bit-identical to calling those one by one.
+#include <vector>
+#include "common.h"
+
+using namespace gs;
+
+extern "C" size_t gs_conv_bn_workspace_bytes(const gs_conv_desc* d) {
+  if (!d) return 0;
+  const size_t a = gs_conv2d_workspace_bytes(d);
+  const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
+  const size_t b = gs_bn_stats_workspace_bytes(rows, d->Co);
+  return a > b ? a : b;
+}
+
+extern "C" int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const float* w,
+                                  const gs_bn_args* bn, const float* residual, int32_t ld_res,
+                                  float* y, float* coeffs, float* z, int32_t ldz, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!d || !bn || !coeffs || !z) return GS_E_NULL;
+  int rc = gs_conv2d_forward(d, x, w, nullptr, nullptr, y, workspace, workspace_bytes, stream);
+  if (rc != GS_OK) return rc;
+  const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
+  const int32_t C = d->Co;
+  if (bn->use_batch_stats) {
+    rc = gs_bn_stats_finalize(y, rows, C, d->ldy, bn->gamma, bn->beta, bn->eps, bn->momentum,
+                              bn->update_running ? bn->running_mean : nullptr,
+                              bn->update_running ? bn->running_var : nullptr, coeffs, workspace,
+                              workspace_bytes, stream);
+  } else {
+    if (!bn->running_mean || !bn->running_var) return GS_E_NULL;
+    rc = gs_bn_eval_coeffs(bn->running_mean, bn->running_var, C, bn->gamma, bn->beta, bn->eps,
+                           coeffs, stream);
+  }
+  if (rc != GS_OK) return rc;
+  return gs_bn_apply(y, rows, C, d->ldy, coeffs, residual, ld_res, bn->relu, z, ldz, stream);
+}
+
+extern "C" int gs_conv_bn_backward(const gs_conv_desc* d, const float* x, const float* w,
+                                   const float* y, const float* z, int32_t ldz,
+                                   const float* coeffs, const gs_bn_args* bn, float* dz,
+                                   int32_t ld_dz, int32_t mask_mode, int32_t write_g, float* dy,
+                                   float* bsums, float* dgamma, float* dbeta, float* dw, float* dx,
+                                   int32_t accumulate_dx, void* workspace, size_t workspace_bytes,
+                                   void* side_workspace, size_t side_workspace_bytes, void* stream,
+                                   void* side_stream) {
+  if (!d || !bn || !coeffs || !dz || !dy || !bsums) return GS_E_NULL;
+  const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
+  const int32_t C = d->Co;
+  int rc = gs_bn_bwd_reduce(dz, ld_dz, y, d->ldy, z, ldz, rows, C, coeffs, mask_mode,
+                            write_g ? dz : nullptr, ld_dz, bsums, workspace, workspace_bytes,
+                            stream);
+  if (rc != GS_OK) return rc;
+  // dz already holds the masked gradient when write_g: the apply pass must not mask again
+  rc = gs_bn_bwd_apply(dz, ld_dz, y, d->ldy, z, ldz, rows, C, coeffs, bsums, (double)rows,
+                       write_g ? 0 : mask_mode, bn->use_batch_stats, dy, d->ldy, dgamma, dbeta,
+                       stream);
+  if (rc != GS_OK) return rc;
+  if (dw) {
+    if (side_stream) {
+      rc = gs_stream_fork(stream, side_stream);   // dy ready
+      if (rc != GS_OK) return rc;
+      rc = gs_conv2d_wgrad(d, x, dy, dw, side_workspace, side_workspace_bytes, side_stream);
+    } else {
+      rc = gs_conv2d_wgrad(d, x, dy, dw, workspace, workspace_bytes, stream);
+    }
+    if (rc != GS_OK) return rc;
+  }
+  if (dx) rc = gs_conv2d_dgrad(d, dy, w, dx, accumulate_dx, workspace, workspace_bytes, stream);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Live timer of the role-1 (bottleneck conv2, K3) forward launches: HIP events recorded on the
+// launch stream around gs_conv2d_forward's kernels (conv + its split-K reduce).  bench.py turns it
+// on for the timed steps and reads the sums after a device synchronize.
+// ------------------------------------------------------------------------------------------
+namespace gs {
+struct K3Prof {
+  bool on = false;
+  std::vector<hipEvent_t> pool;   // pairs: start, stop
+  size_t used = 0;
+  double flops = 0.0;
+};
+static K3Prof g_k3;
+bool k3_prof_on() { return g_k3.on; }
+static hipEvent_t k3_event() {
+  if (g_k3.used == g_k3.pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    g_k3.pool.push_back(e);
+  }
+  return g_k3.pool[g_k3.used++];
+}
+void k3_prof_begin(hipStream_t st) {
+  hipEvent_t e = k3_event();
+  if (e) (void)hipEventRecord(e, st);
+}
+void k3_prof_end(hipStream_t st, double flops) {
+  hipEvent_t e = k3_event();
+  if (e) (void)hipEventRecord(e, st);
+  g_k3.flops += flops;
+}
+}  // namespace gs
+
+extern "C" int gs_k3_timer_enable(int32_t on) {
+  g_k3.on = on != 0;
+  if (on) { g_k3.used = 0; g_k3.flops = 0.0; }
+  return GS_OK;
+}
+
+extern "C" int gs_k3_timer_read(int64_t* launches, double* total_ms, double* total_flops) {
+  if (!launches || !total_ms || !total_flops) return GS_E_NULL;
+  double ms = 0.0;
+  const size_t pairs = g_k3.used / 2;
+  for (size_t i = 0; i < pairs; ++i) {
+    float t = 0.f;
+    hipError_t e = hipEventElapsedTime(&t, g_k3.pool[2 * i], g_k3.pool[2 * i + 1]);
+    if (e != hipSuccess) return static_cast<int>(e);
+    ms += t;
+  }
+  *launches = (int64_t)pairs;
+  *total_ms = ms;
+  *total_flops = g_k3.flops;
+  return GS_OK;
+}

@@ -4,6 +4,11 @@
 using namespace gs;
 
 size_t gs_dgrad_strided_slab_bytes(const gs_conv_desc* d);  // igemm_dgrad.hip
+namespace gs {  // fused_layers.hip: live timer of the role-1 launches
+bool k3_prof_on();
+void k3_prof_begin(hipStream_t st);
+void k3_prof_end(hipStream_t st, double flops);
+}
 
 extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
   if (check_desc(d) != GS_OK) return 0;
@@ -63,6 +68,8 @@ extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const fl
   a.src_bytes = (unsigned)src_b;
   a.dense_bytes = (unsigned)dense_b;
   const bool fast = vec && fast_rows_ok(d->Ci, ks, src_b, dense_b) && getenv("GS_NO_FAST") == nullptr;
+  const bool timed = d->role == GS_CONV_ROLE_BOTTLENECK3X3 && k3_prof_on();
+  if (timed) k3_prof_begin(st);
   if (!vec) launch_rows<false, false, true, 0>(pl, a, st);
   else if (fast && ks == 1) launch_rows_fast<false, 1>(pl, a, st);
   else if (fast && ks == 3 && d->role == GS_CONV_ROLE_BOTTLENECK3X3) launch_rows_fast<false, 3, 1>(pl, a, st);
@@ -76,6 +83,7 @@ extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const fl
     launch_reduce(a, pl.splits, 0, st, d->role == GS_CONV_ROLE_BOTTLENECK3X3 ? 1 : 0);
     rc = launch_status();
   }
+  if (timed) k3_prof_end(st, 2.0 * (double)M * d->Co * d->Ci * d->KH * d->KW);
   return rc;
 }
 

@@ -33,6 +33,14 @@ class ConvDesc(Structure):
                 ("role", c_int32), ("reserved", c_int32)]
 
 
+class BnArgs(Structure):
+    """Mirror of ``gs_bn_args``."""
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p),
+                ("running_var", c_void_p), ("eps", c_float), ("momentum", c_float),
+                ("use_batch_stats", c_int32), ("update_running", c_int32), ("relu", c_int32),
+                ("reserved", c_int32)]
+
+
 class CeDesc(Structure):
     """Mirror of ``gs_ce_desc``."""
     _fields_ = [("N", c_int32), ("h", c_int32), ("w", c_int32), ("Cls", c_int32), ("H", c_int32),
@@ -42,7 +50,7 @@ class CeDesc(Structure):
 
 _P = c_void_p  # device pointers and the stream travel as plain addresses
 _i32, _i64, _f32, _f64, _sz = c_int32, c_int64, c_float, c_double, c_size_t
-_CD, _CE = POINTER(ConvDesc), POINTER(CeDesc)
+_CD, _CE, _BN = POINTER(ConvDesc), POINTER(CeDesc), POINTER(BnArgs)
 
 # name -> (restype, argtypes): one entry per declaration in include/gaiaseg_hip.h
 PROTOTYPES = {
@@ -93,6 +101,13 @@ PROTOTYPES = {
     "gs_confusion_matrix": (_i32, [_P, _P, _i64, _i32, _i32, _P, _P]),
     "gs_sgd_step": (_i32, [_P, _P, _P, _i64, _f32, _f32, _f32, _f32, _P]),
     "gs_debug_force_plan": (_i32, [_i32, _i32, _i32]),
+    "gs_stream_fork": (_i32, [_P, _P]),
+    "gs_conv_bn_workspace_bytes": (_sz, [_CD]),
+    "gs_conv_bn_forward": (_i32, [_CD, _P, _P, _BN, _P, _i32, _P, _P, _P, _i32, _P, _sz, _P]),
+    "gs_conv_bn_backward": (_i32, [_CD, _P, _P, _P, _P, _i32, _P, _BN, _P, _i32, _i32, _i32, _P, _P,
+                                   _P, _P, _P, _P, _i32, _P, _sz, _P, _sz, _P, _P]),
+    "gs_k3_timer_enable": (_i32, [_i32]),
+    "gs_k3_timer_read": (_i32, [POINTER(_i64), POINTER(_f64), POINTER(_f64)]),
 }
 
 _lib = None

@@ -41,8 +41,19 @@ def join_side_streams(dev=None):
     """Make the current stream wait for the weight-gradient kernels queued on the side stream."""
     for key, s in _side_streams.items():
         if _side_dirty.get(key) and (dev is None or (dev.type, dev.index) == key):
-            torch.cuda.current_stream(s.device).wait_stream(s)
+            with torch.cuda.device(s.device):
+                _lib.check(_L().gs_stream_fork(s.cuda_stream, current_stream_ptr()), "gs_stream_fork")
             _side_dirty[key] = False
+
+
+def _side_workspace(need, dev, side):
+    """Split-K scratch of the side stream (allocated under that stream, so the caching allocator
+    orders its reuse against the side stream's kernels)."""
+    buf = _ws_side._buf.get((dev.type, dev.index))
+    if buf is not None and buf.numel() >= need:
+        return buf
+    with torch.cuda.stream(side):
+        return _ws_side.get(need, dev)
 
 
 def _L():
@@ -169,9 +180,8 @@ def conv2d(tape, x, weight, bias, co, stride=1, pad=0, dil=1, out=None, tag=None
             gw = ensure_grad(weight)
             if SIDE_WGRAD:
                 side = _side_stream(dev)
-                side.wait_stream(torch.cuda.current_stream(dev))   # dy (and gw's zeroing) ready
-                with torch.cuda.stream(side):
-                    ws_s = _ws_side.get(need, dev)
+                _lib.check(L.gs_stream_fork(s, side.cuda_stream), "gs_stream_fork")  # dy ready
+                ws_s = _side_workspace(need, dev, side)
                 dy.record_stream(side)
                 x.t.record_stream(side)
                 _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
@@ -259,8 +269,9 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
     dev = x.t.device
     C, rows = x.C, x.rows
     st = current_stream_ptr()
-    buf = torch.empty(7 * C, dtype=torch.float32, device=dev)
-    sums, coeffs = buf[:3 * C], buf[3 * C:]
+    buf = torch.empty(7 * C, dtype=torch.float32, device=dev)   # {sums[3C], coeffs[4C]}
+    sums_ptr = buf.data_ptr()
+    coeffs_ptr = sums_ptr + 12 * C
     gamma = bn.weight.data_ptr() if bn.weight is not None else None
     beta = bn.bias.data_ptr() if bn.bias is not None else None
     count = float(rows)
@@ -277,23 +288,23 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
         if bn.process_group is None:
             # rank-local statistics: partial sums + (sum, finalize) in two launches
             _lib.check(L.gs_bn_stats_finalize(x.ptr, rows, C, x.ld, gamma, beta, bn.eps, mom, rm, rv,
-                                              coeffs.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                                              coeffs_ptr, ws.data_ptr(), ws.numel(), st),
                        "gs_bn_stats_finalize")
         else:
-            _lib.check(L.gs_bn_stats(x.ptr, rows, C, x.ld, sums.data_ptr(), ws.data_ptr(),
+            _lib.check(L.gs_bn_stats(x.ptr, rows, C, x.ld, sums_ptr, ws.data_ptr(),
                                      ws.numel(), st), "gs_bn_stats")
-            merged, count = _sync_stats(sums, count, C, bn.process_group)
+            merged, count = _sync_stats(buf[:3 * C], count, C, bn.process_group)
             _lib.check(L.gs_bn_finalize(merged.data_ptr(), count, C, gamma, beta, bn.eps, mom, rm,
-                                        rv, coeffs.data_ptr(), st), "gs_bn_finalize")
+                                        rv, coeffs_ptr, st), "gs_bn_finalize")
         if bn.training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked()  # host-side counter: no device op per BN per step
     else:
         _lib.check(L.gs_bn_eval_coeffs(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), C,
-                                       gamma, beta, bn.eps, coeffs.data_ptr(), st),
+                                       gamma, beta, bn.eps, coeffs_ptr, st),
                    "gs_bn_eval_coeffs")
     if out is None:
         out = x if (inplace and not tape.enabled) else Act.empty(x.N, x.H, x.W, C, dev)
-    _lib.check(L.gs_bn_apply(x.ptr, rows, C, x.ld, coeffs.data_ptr(),
+    _lib.check(L.gs_bn_apply(x.ptr, rows, C, x.ld, coeffs_ptr,
                              residual.ptr if residual is not None else None,
                              residual.ld if residual is not None else 0, 1 if relu else 0,
                              out.ptr, out.ld, st), "gs_bn_apply")
@@ -303,6 +314,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
         if dy is None:
             return
         s = current_stream_ptr()
+        keep = buf  # noqa: F841 -- the closure owns the coefficient storage behind coeffs_ptr
         mask = 0 if not relu else (2 if residual is not None else 1)
         nbw = L.gs_bn_bwd_workspace_bytes(rows, C)
         wsb = _ws.get(nbw, dev)
@@ -310,7 +322,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
         # the masked gradient g is also the gradient of the identity branch: write it in place
         want_g = residual is not None and residual.requires_grad and relu
         _lib.check(L.gs_bn_bwd_reduce(dy.data_ptr(), dy.stride(2),
-                                      x.ptr, x.ld, out.ptr, out.ld, rows, C, coeffs.data_ptr(),
+                                      x.ptr, x.ld, out.ptr, out.ld, rows, C, coeffs_ptr,
                                       mask, dy.data_ptr() if want_g else None, dy.stride(2),
                                       bsums.data_ptr(), wsb.data_ptr(), wsb.numel(), s),
                    "gs_bn_bwd_reduce")
@@ -327,7 +339,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
             raise RuntimeError("BN input has more than one consumer; unsupported")
         x.new_grad() if x.parent is None else _alloc_parent_grad(x)
         _lib.check(L.gs_bn_bwd_apply(dy.data_ptr(), dy.stride(2), x.ptr, x.ld, out.ptr, out.ld,
-                                     rows, C, coeffs.data_ptr(), bsums.data_ptr(), bcount,
+                                     rows, C, coeffs_ptr, bsums.data_ptr(), bcount,
                                      mask_apply, 1 if use_batch else 0, x.g.data_ptr(),
                                      x.g.stride(2), gw.data_ptr() if wgrad else None,
                                      gb.data_ptr() if bgrad else None, s), "gs_bn_bwd_apply")
@@ -347,6 +359,114 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
                     acc = 1
                 _lib.check(L.gs_copy2d(src.data_ptr(), src.stride(2), residual.g.data_ptr(),
                                        residual.g.stride(2), rows, C, 1.0, acc, s), "gs_copy2d")
+
+    tape.record(backward)
+    return out
+
+
+def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
+            tag=None):
+    """z = act(BN(conv(x, weight[:co, :x.C])) (+ residual)) through ONE library call per direction
+    (gs_conv_bn_forward / gs_conv_bn_backward): same kernels, same results as conv2d() followed by
+    batchnorm(), a third of the host work.  Rank-local BatchNorm only (``bn.process_group`` None);
+    the conv has no bias."""
+    L = _L()
+    co_eff = round_up(co, 4)
+    dev = x.t.device
+    kh, kw = weight.shape[2], weight.shape[3]
+    if x.nchw_image:
+        n, _, h, w = x.t.shape
+    else:
+        n, h, w = x.N, x.H, x.W
+    ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(w, kw, stride, pad, dil)
+    rows = n * ho * wo
+    use_batch = bn.training or bn.running_mean is None
+    if use_batch and rows <= 1:
+        raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                         % ((n, co, ho, wo),))
+    y = Act.empty(n, ho, wo, co, dev)
+    if out is None:
+        out = Act.empty(n, ho, wo, co, dev)
+    d = _conv_desc(x, weight, co_eff, stride, pad, dil, y.ld, role=1 if tag == "k3" else 0)
+    C = co_eff
+    if y.C != C:   # channel counts that are not multiples of 4 keep the two-step path
+        raise ValueError("conv_bn needs an output width that is a multiple of 4, got %d" % co)
+    args = _lib.BnArgs()
+    args.gamma = bn.weight.data_ptr() if bn.weight is not None else None
+    args.beta = bn.bias.data_ptr() if bn.bias is not None else None
+    args.running_mean = bn.running_mean.data_ptr() if bn.running_mean is not None else None
+    args.running_var = bn.running_var.data_ptr() if bn.running_var is not None else None
+    args.eps = bn.eps
+    args.momentum = bn.momentum if bn.momentum is not None else 0.1
+    args.use_batch_stats = 1 if use_batch else 0
+    args.update_running = 1 if (bn.training and bn.running_mean is not None) else 0
+    args.relu = 1 if relu else 0
+    coeffs = torch.empty(4 * C, dtype=torch.float32, device=dev)
+    need = L.gs_conv_bn_workspace_bytes(ctypes.byref(d))
+    ws = _ws.get(need, dev)
+    _lib.check(L.gs_conv_bn_forward(ctypes.byref(d), x.ptr, weight.data_ptr(), ctypes.byref(args),
+                                    residual.ptr if residual is not None else None,
+                                    residual.ld if residual is not None else 0, y.ptr,
+                                    coeffs.data_ptr(), out.ptr, out.ld, ws.data_ptr(), ws.numel(),
+                                    current_stream_ptr()), "gs_conv_bn_forward")
+    if use_batch and bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked()
+
+    def backward():
+        dz = out.g
+        if dz is None:
+            return
+        s = current_stream_ptr()
+        mask = 0 if not relu else (2 if residual is not None else 1)
+        want_g = residual is not None and residual.requires_grad and relu
+        wgrad_bn = bn.weight is not None and bn.weight.requires_grad
+        bgrad_bn = bn.bias is not None and bn.bias.requires_grad
+        ggamma = ensure_grad(bn.weight) if wgrad_bn else None
+        gbeta = ensure_grad(bn.bias) if bgrad_bn else None
+        gw = ensure_grad(weight) if weight.requires_grad else None
+        dy = torch.empty_like(y.t)
+        bsums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        acc = 0
+        dx_ptr = None
+        if x.requires_grad:
+            acc = 1 if x.g is not None else 0
+            if not acc:
+                x.new_grad() if x.parent is None else _alloc_parent_grad(x)
+            dx_ptr = x.g.data_ptr()
+        ws_b = _ws.get(need, dev)
+        side = _side_stream(dev) if (SIDE_WGRAD and gw is not None) else None
+        if side is not None:
+            ws_s = _side_workspace(need, dev, side)
+            dy.record_stream(side)
+            x.t.record_stream(side)
+        _lib.check(L.gs_conv_bn_backward(
+            ctypes.byref(d), x.ptr, weight.data_ptr(), y.ptr, out.ptr, out.ld, coeffs.data_ptr(),
+            ctypes.byref(args), dz.data_ptr(), dz.stride(2), mask, 1 if want_g else 0,
+            dy.data_ptr(), bsums.data_ptr(), ggamma.data_ptr() if wgrad_bn else None,
+            gbeta.data_ptr() if bgrad_bn else None, gw.data_ptr() if gw is not None else None,
+            dx_ptr, acc, ws_b.data_ptr(), ws_b.numel(),
+            ws_s.data_ptr() if side is not None else None, ws_s.numel() if side is not None else 0,
+            s, side.cuda_stream if side is not None else None), "gs_conv_bn_backward")
+        if side is not None:
+            _side_dirty[(dev.type, dev.index)] = True
+        if wgrad_bn:
+            _notify(bn.weight)
+        if bgrad_bn:
+            _notify(bn.bias)
+        if gw is not None:
+            _notify(weight)
+        if residual is not None and residual.requires_grad:
+            src = dz  # masked (relu) or plain (no relu) upstream gradient
+            if residual.g is None and residual.parent is None and src.stride() == residual.t.stride():
+                residual.g = src
+            else:
+                if residual.g is None:
+                    residual.new_grad() if residual.parent is None else _alloc_parent_grad(residual)
+                    racc = 0 if residual.parent is None else 1
+                else:
+                    racc = 1
+                _lib.check(L.gs_copy2d(src.data_ptr(), src.stride(2), residual.g.data_ptr(),
+                                       residual.g.stride(2), rows, C, 1.0, racc, s), "gs_copy2d")
 
     tape.record(backward)
     return out

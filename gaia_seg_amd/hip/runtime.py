@@ -16,7 +16,14 @@ import torch
 from . import lib as _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream_ptr():
+    """hipStream_t of torch's current stream on the current device (raw handle: this is called
+    once per kernel launch, torch.cuda.current_stream() costs ~9 us of host time each)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -66,7 +73,8 @@ class Act:
     ``g`` is its gradient (same shape / layout), filled during the backward replay.
     ``nchw_image`` marks the network input, which is read in place through NCHW strides."""
 
-    __slots__ = ("t", "_g", "requires_grad", "parent", "c0", "nchw_image")
+    __slots__ = ("t", "_g", "requires_grad", "parent", "c0", "nchw_image",
+                 "N", "H", "W", "C", "ld", "rows", "ptr")
 
     def __init__(self, t, requires_grad=True, parent=None, c0=0, nchw_image=False):
         self.t = t
@@ -75,35 +83,13 @@ class Act:
         self.parent = parent
         self.c0 = c0
         self.nchw_image = nchw_image
-
-    # ---- geometry ----
-    @property
-    def N(self):
-        return self.t.shape[0]
-
-    @property
-    def H(self):
-        return self.t.shape[1]
-
-    @property
-    def W(self):
-        return self.t.shape[2]
-
-    @property
-    def C(self):
-        return self.t.shape[3]
-
-    @property
-    def ld(self):
-        return self.t.stride(2)
-
-    @property
-    def rows(self):
-        return self.t.shape[0] * self.t.shape[1] * self.t.shape[2]
-
-    @property
-    def ptr(self):
-        return self.t.data_ptr()
+        # geometry, fixed for the life of the object (t is never rebound): plain attributes, these
+        # are read several times per kernel launch
+        shp = t.shape
+        self.N, self.H, self.W, self.C = shp[0], shp[1], shp[2], shp[3]
+        self.ld = t.stride(2)
+        self.rows = shp[0] * shp[1] * shp[2]
+        self.ptr = t.data_ptr()
 
     # ---- gradient ----
     @property
@@ -208,6 +194,12 @@ class Tape:
         _ops.join_side_streams()   # weight gradients queued on the side stream
 
 
+BACKWARD_PROFILE = None
+if __import__("os").environ.get("GS_CPROFILE"):
+    import cProfile
+    BACKWARD_PROFILE = cProfile.Profile()
+
+
 class _TapeFunction(torch.autograd.Function):
     """One autograd node for a whole module forward (backbone, head).
 
@@ -228,6 +220,16 @@ class _TapeFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        if BACKWARD_PROFILE is not None:   # diagnostics (GS_CPROFILE): autograd runs this thread
+            BACKWARD_PROFILE.enable()
+            try:
+                return _TapeFunction._backward(ctx, *grads)
+            finally:
+                BACKWARD_PROFILE.disable()
+        return _TapeFunction._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, *grads):
         for o, g in zip(ctx.outs, grads):
             if g is not None:
                 o.set_grad_from_nchw(g)

@@ -158,6 +158,53 @@ int gs_bn_bwd_apply(const float* dy, int32_t ld_dy, const float* x, int32_t ldx,
                     float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* conv -> BatchNorm (+ residual) (+ ReLU) issued by ONE host call per direction               */
+/* ------------------------------------------------------------------------------------------ */
+/* Replaces the module chain conv -> norm -> activate of gaiavision DynamicConvModule and of each
+ * conv/bn pair of DynamicBottleneck (gaiaseg/models/utils/dynamic_res_layer.py:84-125,
+ * gaiaseg/models/backbones/dynamic_resnet.py:255-302, decode heads' ConvModules) for rank-local
+ * BatchNorm.  Pure composition of gs_conv2d_*, gs_bn_* and gs_stream_fork above: bit-identical to
+ * calling them one by one; it exists because one host call per module costs as much host time as
+ * the kernels cost GPU time on this path. */
+typedef struct gs_bn_args {
+  const float* gamma;        /* [>= C] or NULL (1)                                              */
+  const float* beta;         /* [>= C] or NULL (0)                                              */
+  float* running_mean;       /* [>= C] or NULL                                                  */
+  float* running_var;        /* [>= C] or NULL                                                  */
+  float eps, momentum;
+  int32_t use_batch_stats;   /* 1: statistics of this batch (training); 0: running statistics   */
+  int32_t update_running;    /* 1: update running_mean / running_var (training mode)            */
+  int32_t relu;              /* ReLU after the BN (+ residual)                                  */
+  int32_t reserved;          /* must be 0                                                       */
+} gs_bn_args;
+/* max(gs_conv2d_workspace_bytes, gs_bn_stats_workspace_bytes) for this conv's output */
+size_t gs_conv_bn_workspace_bytes(const gs_conv_desc* d);
+/* y = conv(x, w) [N*Ho*Wo][ldy] (kept for backward); coeffs[4*Co] (kept for backward);
+ * z = relu?(BN(y) (+ residual)) with pixel stride ldz.  The conv has no bias (norm follows). */
+int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const float* w, const gs_bn_args* bn,
+                       const float* residual, int32_t ld_res, float* y, float* coeffs, float* z,
+                       int32_t ldz, void* workspace, size_t workspace_bytes, void* stream);
+/* dz: gradient of z (in/out: overwritten with the masked gradient when write_g != 0 — that is the
+ * gradient of the identity branch of a bottleneck); mask_mode as gs_bn_bwd_reduce (z is the saved
+ * post-activation tensor for mode 2).  dy: scratch [N*Ho*Wo][ldy] receiving the gradient of the conv
+ * output; bsums: scratch [2*Co].  dgamma/dbeta/dw/dx may be NULL (not needed).  side_stream != NULL
+ * runs the weight gradient there (forked after dy is complete; the caller joins it later with
+ * gs_stream_fork(side_stream, stream)) using side_workspace. */
+int gs_conv_bn_backward(const gs_conv_desc* d, const float* x, const float* w, const float* y,
+                        const float* z, int32_t ldz, const float* coeffs, const gs_bn_args* bn,
+                        float* dz, int32_t ld_dz, int32_t mask_mode, int32_t write_g, float* dy,
+                        float* bsums, float* dgamma, float* dbeta, float* dw, float* dx,
+                        int32_t accumulate_dx, void* workspace, size_t workspace_bytes,
+                        void* side_workspace, size_t side_workspace_bytes, void* stream,
+                        void* side_stream);
+
+/* Live timer of the gs_conv2d_forward launches with role GS_CONV_ROLE_BOTTLENECK3X3 (HIP events on
+ * the launch stream around the conv kernel and its split-K reduce): bench.py's `roofline`.
+ * enable(1) resets and starts, enable(0) stops; read after a device synchronize. */
+int gs_k3_timer_enable(int32_t on);
+int gs_k3_timer_read(int64_t* launches, double* total_ms, double* total_flops);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Pooling — K5, K7                                                                            */
 /* ------------------------------------------------------------------------------------------ */
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (dynamic_resnet.py:302,413), generic k/s/p.
@@ -296,6 +343,14 @@ int gs_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
 /* order of split-K changes).                                                                  */
 /* ------------------------------------------------------------------------------------------ */
 int gs_debug_force_plan(int32_t bm, int32_t bn, int32_t splits);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Stream fork / join: work enqueued on `to` after this call waits for everything enqueued on  */
+/* `from` before it (hipEventRecord + hipStreamWaitEvent on an internal event ring).  Used to   */
+/* run the weight-gradient kernels on a side stream beside BN-backward / dgrad (the reference   */
+/* runs all of backward on one stream: torch autograd, gaiaseg/apis/train.py:88-96).            */
+/* ------------------------------------------------------------------------------------------ */
+int gs_stream_fork(void* from_stream, void* to_stream);
 
 #ifdef __cplusplus
 }
