@@ -1,0 +1,36 @@
+// Internal (C++ linkage) interfaces between the conv, BatchNorm and fused-layer translation units.
+#pragma once
+#include "common.h"
+
+namespace gs {
+
+struct ConvFwdInfo {
+  int mode;          // 0: y complete; 1: per-tile BN partials written; 2: split-K slabs left to reduce
+  int splits, tiles_m, bm;
+  float* slab;       // mode 2: [splits][M][Co]
+  size_t slab_bytes;
+  bool timed;        // a K3 timer interval is open (mode 2: the caller closes it)
+  double flops;
+};
+
+// igemm_fwd.hip
+int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, const float* bias,
+                        const float* addend, float* y, void* workspace, size_t workspace_bytes,
+                        void* stream, bool want_stats, ConvFwdInfo* info);
+
+// norm.hip
+size_t bn_fused_reduce_bytes(long rows, int C);
+int bn_reduce_stats_finalize(const float* slab, int splits, long rows, int C, float* y, int ldy,
+                             const float* gamma, const float* beta, float eps, float momentum,
+                             float* running_mean, float* running_var, float* coeffs, float* part,
+                             size_t part_bytes, hipStream_t st, int role, bool timed, double flops);
+int bn_tile_finalize(const float* part, int np, int bm, long rows, int C, const float* gamma,
+                     const float* beta, float eps, float momentum, float* running_mean,
+                     float* running_var, float* coeffs, hipStream_t st);
+
+// fused_layers.hip: live timer of the role-1 (K3) forward launches
+bool k3_prof_on();
+void k3_prof_begin(hipStream_t st);
+void k3_prof_end(hipStream_t st, double flops);
+
+}  // namespace gs

@@ -11,15 +11,25 @@
 // operator entry points of this library: results are bit-identical to calling those one by one.
 #include <vector>
 #include "common.h"
+#include "fused_internal.h"
 
 using namespace gs;
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" size_t gs_conv_bn_workspace_bytes(const gs_conv_desc* d) {
   if (!d) return 0;
   const size_t a = gs_conv2d_workspace_bytes(d);
   const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
   const size_t b = gs_bn_stats_workspace_bytes(rows, d->Co);
-  return a > b ? a : b;
+  // split-K slabs followed by the partials of the fused reduce + statistics pass; or the per-tile
+  // partials of the conv epilogue (3 floats per channel and 64-row tile)
+  const size_t fused = align256(a) + bn_fused_reduce_bytes(rows, d->Co);
+  const size_t tiles = (size_t)3 * d->Co * ((rows + 63) / 64) * sizeof(float);
+  size_t m = a > b ? a : b;
+  if (fused > m) m = fused;
+  if (tiles > m) m = tiles;
+  return m;
 }
 
 extern "C" int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const float* w,
@@ -27,11 +37,28 @@ extern "C" int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const f
                                   float* y, float* coeffs, float* z, int32_t ldz, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   if (!d || !bn || !coeffs || !z) return GS_E_NULL;
-  int rc = gs_conv2d_forward(d, x, w, nullptr, nullptr, y, workspace, workspace_bytes, stream);
+  static const bool no_fuse = getenv("GS_NO_STATS_FUSION") != nullptr;
+  ConvFwdInfo info{};
+  int rc = conv2d_forward_impl(d, x, w, nullptr, nullptr, y, workspace, workspace_bytes, stream,
+                               bn->use_batch_stats && !no_fuse, &info);
   if (rc != GS_OK) return rc;
   const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
   const int32_t C = d->Co;
-  if (bn->use_batch_stats) {
+  float* rm = bn->update_running ? bn->running_mean : nullptr;
+  float* rv = bn->update_running ? bn->running_var : nullptr;
+  if (info.mode == 1) {
+    rc = bn_tile_finalize(static_cast<const float*>(workspace), info.tiles_m, info.bm, rows, C,
+                          bn->gamma, bn->beta, bn->eps, bn->momentum, rm, rv, coeffs,
+                          as_stream(stream));
+  } else if (info.mode == 2) {
+    const size_t off = align256(info.slab_bytes);
+    if (off > workspace_bytes) return GS_E_WORKSPACE;
+    rc = bn_reduce_stats_finalize(info.slab, info.splits, rows, C, y, d->ldy, bn->gamma, bn->beta,
+                                  bn->eps, bn->momentum, rm, rv, coeffs,
+                                  reinterpret_cast<float*>(static_cast<char*>(workspace) + off),
+                                  workspace_bytes - off, as_stream(stream), d->role, info.timed,
+                                  info.flops);
+  } else if (bn->use_batch_stats) {
     rc = gs_bn_stats_finalize(y, rows, C, d->ldy, bn->gamma, bn->beta, bn->eps, bn->momentum,
                               bn->update_running ? bn->running_mean : nullptr,
                               bn->update_running ? bn->running_var : nullptr, coeffs, workspace,

@@ -59,6 +59,9 @@ struct IgemmArgs {
   int o_s, o_ph, o_pw, o_Hq, o_Wq, o_H, o_W;
   // fast kernels: 1-D grid of tiles x splits, split-major; tile_order 1 = tm fastest
   int nsplits, tile_order;
+  // forward only: per-tile BatchNorm partial sums written by the epilogue (NULL = off), quad-major
+  // {s1, s2, shift}[C/4][tiles_m] float4 with shift = the tile's first row (see rows_epilogue)
+  float* tile_stats;
 };
 
 // pixel index of GEMM row m in the output tensor
@@ -87,7 +90,8 @@ struct Tile {
   static constexpr int CCH = BN < 64 ? BN : 64;  // epilogue column chunk
   static constexpr int PC = CCH + 4;
   static constexpr int C_SZ = BM * PC;
-  static constexpr int LDSF = (2 * STAGE > C_SZ) ? 2 * STAGE : C_SZ;
+  // (+512 floats behind the C image: scratch of the epilogue's per-tile BatchNorm partial sums)
+  static constexpr int LDSF = (2 * STAGE > C_SZ + 512) ? 2 * STAGE : C_SZ + 512;
   static constexpr int WM = BM / 4;   // rows per wave
   static constexpr int TM = WM / 16;  // 16x16 tiles per wave along M
   static constexpr int TN = BN / 16;
@@ -365,6 +369,42 @@ __device__ __forceinline__ void rows_epilogue(
           if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
           *reinterpret_cast<f32x4*>(o) = v;
         }
+      }
+    }
+    if (p.tile_stats && !p.slab) {
+      // BatchNorm statistics of the tile while it is still in LDS (the BN that follows every conv
+      // of this path would otherwise re-read the whole output from HBM): per column
+      // s1 = sum(v - shift), s2 = sum (v - shift)^2 over the tile's rows, shift = its first row
+      // (well conditioned per tile; bn_tile_finalize merges the tiles with Chan's formula).
+      constexpr int G = NT / T::CCH;
+      const int c = t % T::CCH, rg = t / T::CCH;
+      float* red = lds + T::C_SZ;   // [2][G][CCH]
+      const int colg = n0 + ch * T::CCH + c;
+      const bool cv = rg < G && (ch * T::CCH + c) < BN && colg < p.Nn;
+      const int nrows = min(BM, p.M - m0);
+      float s1 = 0.f, s2 = 0.f;
+      const float shift = Cs[c];
+      if (cv)
+        for (int r = rg; r < nrows; r += G) {
+          const float v = Cs[r * T::PC + c] - shift;
+          s1 += v;
+          s2 += v * v;
+        }
+      if (rg < G) {
+        red[rg * T::CCH + c] = s1;
+        red[(G + rg) * T::CCH + c] = s2;
+      }
+      __syncthreads();
+      if (cv && rg == 0) {
+        for (int g = 1; g < G; ++g) {
+          s1 += red[g * T::CCH + c];
+          s2 += red[(G + g) * T::CCH + c];
+        }
+        const long C4 = p.Nn >> 2, np = p.tiles_m, tm = m0 / BM;
+        const int cq = colg >> 2, e = colg & 3;
+        p.tile_stats[((0 * C4 + cq) * np + tm) * 4 + e] = s1;
+        p.tile_stats[((1 * C4 + cq) * np + tm) * 4 + e] = s2;
+        p.tile_stats[((2 * C4 + cq) * np + tm) * 4 + e] = shift;
       }
     }
   }

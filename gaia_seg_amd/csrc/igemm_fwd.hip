@@ -4,11 +4,7 @@
 using namespace gs;
 
 size_t gs_dgrad_strided_slab_bytes(const gs_conv_desc* d);  // igemm_dgrad.hip
-namespace gs {  // fused_layers.hip: live timer of the role-1 launches
-bool k3_prof_on();
-void k3_prof_begin(hipStream_t st);
-void k3_prof_end(hipStream_t st, double flops);
-}
+#include "fused_internal.h"
 
 extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
   if (check_desc(d) != GS_OK) return 0;
@@ -29,9 +25,15 @@ extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
   return b;
 }
 
-extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const float* w,
-                                 const float* bias, const float* addend, float* y, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+namespace gs {
+// Forward with the options of the fused conv+BN entry point (fused_layers.hip):
+//   want_stats: the caller wants BatchNorm batch statistics of y.  Without split-K the epilogue
+//     writes per-tile partials to the start of `workspace` (info->mode = 1); with split-K the
+//     reduce launch is left to the caller, who fuses it with the statistics pass (mode = 2).
+//     mode = 0: y is complete, no statistics were produced.
+int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, const float* bias,
+                        const float* addend, float* y, void* workspace, size_t workspace_bytes,
+                        void* stream, bool want_stats, ConvFwdInfo* info) {
   int rc = check_desc(d);
   if (rc != GS_OK) return rc;
   if (!x || !w || !y) return GS_E_NULL;
@@ -70,6 +72,25 @@ extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const fl
   const bool fast = vec && fast_rows_ok(d->Ci, ks, src_b, dense_b) && getenv("GS_NO_FAST") == nullptr;
   const bool timed = d->role == GS_CONV_ROLE_BOTTLENECK3X3 && k3_prof_on();
   if (timed) k3_prof_begin(st);
+  const double flops = 2.0 * (double)M * d->Co * d->Ci * d->KH * d->KW;
+  int mode = 0;
+  if (want_stats && info && fast && !bias && !addend) {
+    if (pl.splits == 1) {
+      const size_t part_b = (size_t)3 * d->Co * pl.tiles_m * sizeof(float);
+      if (workspace && part_b <= workspace_bytes && aligned16(workspace)) {
+        a.tile_stats = static_cast<float*>(workspace);
+        mode = 1;
+      }
+    } else if (d->ldy >= d->Co && !timed) {
+      // (while the K3 timer runs, a split bottleneck conv2 keeps its own reduce launch, so that
+      // the timed interval is exactly the conv and its slab reduction)
+      mode = 2;
+    }
+  }
+  if (info) {
+    info->mode = mode; info->splits = pl.splits; info->tiles_m = pl.tiles_m; info->bm = pl.bm;
+    info->slab = a.slab; info->slab_bytes = need; info->timed = timed; info->flops = flops;
+  }
   if (!vec) launch_rows<false, false, true, 0>(pl, a, st);
   else if (fast && ks == 1) launch_rows_fast<false, 1>(pl, a, st);
   else if (fast && ks == 3 && d->role == GS_CONV_ROLE_BOTTLENECK3X3) launch_rows_fast<false, 3, 1>(pl, a, st);
@@ -79,11 +100,20 @@ extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const fl
   else launch_rows<false, false, false, 0>(pl, a, st);
   rc = launch_status();
   if (rc != GS_OK) return rc;
+  if (mode == 2) return rc;   // the caller reduces the slabs (and closes the K3 timer)
   if (pl.splits > 1) {
     launch_reduce(a, pl.splits, 0, st, d->role == GS_CONV_ROLE_BOTTLENECK3X3 ? 1 : 0);
     rc = launch_status();
   }
-  if (timed) k3_prof_end(st, 2.0 * (double)M * d->Co * d->Ci * d->KH * d->KW);
+  if (timed) k3_prof_end(st, flops);
   return rc;
+}
+}  // namespace gs
+
+extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const float* w,
+                                 const float* bias, const float* addend, float* y, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  return conv2d_forward_impl(d, x, w, bias, addend, y, workspace, workspace_bytes, stream, false,
+                             nullptr);
 }
 

@@ -12,6 +12,7 @@
 // channel), hence bit-reproducible run to run.
 #include <algorithm>
 #include "common.h"
+#include "fused_internal.h"
 
 namespace gs {
 
@@ -371,6 +372,135 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     reinterpret_cast<f32x4*>(part)[(long)m.cq * gridDim.x + blockIdx.x] = s1;
 }
 
+
+// ---------------- statistics fused with the producing convolution ----------------
+// (a) conv without split-K: the conv epilogue wrote per-tile partials {s1, s2, shift} (quad-major,
+//     igemm_core.h rows_epilogue).  Merge the tiles exactly (Chan et al.): tile mean
+//     m_t = shift_t + s1_t/n_t, tile M2_t = s2_t - s1_t^2/n_t; mean = sum n_t m_t / N,
+//     M2 = sum [M2_t + n_t (m_t - mean)^2].  Two fixed-order block sums in double.
+__device__ __forceinline__ void block_sum_d4(double (&a)[4], double* sh /* [16] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] += __shfl_xor(a[e], off, 64);
+  __syncthreads();   // sh may still be read from a previous call
+  if (lane == 0)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sh[wave * 4 + e] = a[e];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a[e] = ((sh[e] + sh[4 + e]) + sh[8 + e]) + sh[12 + e];
+}
+
+__global__ __launch_bounds__(256) void bn_tile_finalize_kernel(
+    const float* __restrict__ part, int np, int bm, long M, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+    float* running_var, float* __restrict__ coeffs, int n_last, double inv_full, double inv_last,
+    double inv_M) {
+  __shared__ double sh[16];
+  const int q = blockIdx.x, C4 = C >> 2, t = threadIdx.x;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+  const f32x4* s1p = p4 + (0L * C4 + q) * np;
+  const f32x4* s2p = p4 + (1L * C4 + q) * np;
+  const f32x4* shp = p4 + (2L * C4 + q) * np;
+  // every tile has bm rows except possibly the last one (n_last); the reciprocals come from the
+  // host (no fp64 division per thread).  NOTE: no private array may be indexed by a run-time value
+  // in this kernel: the compiler would move it to LDS, address it with the flat work-item id, and
+  // fetch the workgroup size from the dispatch packet in HOST memory in every wave (measured:
+  // 30 us instead of 5 for 512 workgroups).
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int p = t; p < np; p += 256) {
+    const double n = (double)(p == np - 1 ? n_last : bm);
+    const f32x4 s1 = s1p[p], shv = shp[p];
+    a0 += n * (double)shv[0] + (double)s1[0];   // n_t * m_t
+    a1 += n * (double)shv[1] + (double)s1[1];
+    a2 += n * (double)shv[2] + (double)s1[2];
+    a3 += n * (double)shv[3] + (double)s1[3];
+  }
+  {
+    double a[4] = {a0, a1, a2, a3};
+    block_sum_d4(a, sh);
+    a0 = a[0] * inv_M; a1 = a[1] * inv_M; a2 = a[2] * inv_M; a3 = a[3] * inv_M;   // means
+  }
+  double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  for (int p = t; p < np; p += 256) {
+    const double n = (double)(p == np - 1 ? n_last : bm);
+    const double inv_n = p == np - 1 ? inv_last : inv_full;
+    const f32x4 s1 = s1p[p], s2 = s2p[p], shv = shp[p];
+#define GS_M2(E, MEAN, ACC)                                        \
+    {                                                              \
+      const double d1 = (double)s1[E] * inv_n;                     \
+      const double dm = (double)shv[E] + d1 - MEAN;                \
+      ACC += ((double)s2[E] - (double)s1[E] * d1) + n * dm * dm;   \
+    }
+    GS_M2(0, a0, b0) GS_M2(1, a1, b1) GS_M2(2, a2, b2) GS_M2(3, a3, b3)
+#undef GS_M2
+  }
+  {
+    double b[4] = {b0, b1, b2, b3};
+    block_sum_d4(b, sh);
+    b0 = b[0]; b1 = b[1]; b2 = b[2]; b3 = b[3];
+  }
+  if (t == 0) {
+    const int c0 = q * 4;
+#define GS_FIN(E, MU, M2)                                                                        \
+    {                                                                                             \
+      const int c = c0 + E;                                                                       \
+      double var = M2 * inv_M;                                                                    \
+      if (var < 0.0) var = 0.0;                                                                   \
+      const double invstd = 1.0 / sqrt(var + (double)eps);                                        \
+      coeffs[c] = (float)((double)(gamma ? gamma[c] : 1.f) * invstd);                             \
+      coeffs[C + c] = beta ? beta[c] : 0.f;                                                       \
+      coeffs[2 * C + c] = (float)MU;                                                              \
+      coeffs[3 * C + c] = (float)invstd;                                                          \
+      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)MU; \
+      if (running_var) {                                                                          \
+        const double unbiased = M > 1 ? var * (double)M / ((double)M - 1.0) : var;                \
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;          \
+      }                                                                                           \
+    }
+    GS_FIN(0, a0, b0) GS_FIN(1, a1, b1) GS_FIN(2, a2, b2) GS_FIN(3, a3, b3)
+#undef GS_FIN
+  }
+}
+
+// (b) conv with split-K: the fixed-order sum of the partial slabs (igemm_core.h
+//     splitk_reduce_kernel, same order: split 0 first), the store of y AND the shifted sums of
+//     bn_stats_partial_kernel in one pass, with that kernel's geometry and shift (= y[0, :],
+//     recomputed from the slabs): bit-identical to reduce followed by bn_stats.
+template <int ROLE>   // ROLE only names the instantiation (see gs_conv_desc::role)
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(
+    const float* __restrict__ slab, int splits, long rows, int C, float* __restrict__ y, int ldy,
+    long rows_per_block, float* __restrict__ part) {
+  __shared__ f32x4 sh[512];
+  const int C4 = C >> 2;
+  const ColMap m = col_map(C4);
+  f32x4 s1{0.f, 0.f, 0.f, 0.f}, s2{0.f, 0.f, 0.f, 0.f};
+  if (m.active) {
+    const long zs = rows * C;   // slab stride
+    f32x4 shift = *reinterpret_cast<const f32x4*>(slab + m.cq * 4);
+    for (int z = 1; z < splits; ++z) shift += *reinterpret_cast<const f32x4*>(slab + z * zs + m.cq * 4);
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(r0 + rows_per_block, rows);
+    for (long r = r0 + m.rr; r < r1; r += m.rpi) {
+      const float* sp = slab + r * C + m.cq * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+      for (int z = 1; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(sp + z * zs);
+      *reinterpret_cast<f32x4*>(y + r * ldy + m.cq * 4) = v;
+      v -= shift;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  block_reduce_rows(s1, s2, m, C4, sh);
+  if (m.active && m.rr == 0) {
+    f32x4* part4 = reinterpret_cast<f32x4*>(part);
+    part4[(long)m.cq * gridDim.x + blockIdx.x] = s1;
+    part4[((long)C4 + m.cq) * gridDim.x + blockIdx.x] = s2;
+  }
+}
+
 // ---- host helpers ----
 struct RedGeom {
   int gx, gy;
@@ -412,6 +542,42 @@ static int check_rows(const void* p, long rows, int C, int ld) {
 }  // namespace gs
 
 using namespace gs;
+
+// ---- internal entry points used by fused_layers.hip ----
+namespace gs {
+size_t bn_fused_reduce_bytes(long rows, int C) {
+  const RedGeom g = red_geom(rows, C);
+  return (size_t)g.gx * 2 * C * sizeof(float);
+}
+// y = sum of `splits` slabs [rows][C]; coeffs from the batch statistics of y (rank-local BN)
+int bn_reduce_stats_finalize(const float* slab, int splits, long rows, int C, float* y, int ldy,
+                             const float* gamma, const float* beta, float eps, float momentum,
+                             float* running_mean, float* running_var, float* coeffs, float* part,
+                             size_t part_bytes, hipStream_t st, int role, bool timed, double flops) {
+  const RedGeom g = red_geom(rows, C);
+  if ((size_t)g.gx * 2 * C * sizeof(float) > part_bytes) return GS_E_WORKSPACE;
+  if (role == 1)
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel<1>, dim3(g.gx, g.gy), dim3(256), 0, st, slab,
+                       splits, rows, C, y, ldy, g.rows_per_block, part);
+  else
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel<0>, dim3(g.gx, g.gy), dim3(256), 0, st, slab,
+                       splits, rows, C, y, ldy, g.rows_per_block, part);
+  if (timed) k3_prof_end(st, flops);   // the K3 interval covers the conv and its slab reduction
+  hipLaunchKernelGGL(bn_sum_finalize_kernel, dim3(C / 4), dim3(256), 0, st, part, g.gx, C, y,
+                     (double)rows, gamma, beta, eps, momentum, running_mean, running_var, coeffs);
+  return launch_status();
+}
+// coeffs from the per-tile partials the conv epilogue wrote
+int bn_tile_finalize(const float* part, int np, int bm, long rows, int C, const float* gamma,
+                     const float* beta, float eps, float momentum, float* running_mean,
+                     float* running_var, float* coeffs, hipStream_t st) {
+  const int n_last = (int)(rows - (long)(np - 1) * bm);
+  hipLaunchKernelGGL(bn_tile_finalize_kernel, dim3(C / 4), dim3(256), 0, st, part, np, bm, rows, C,
+                     gamma, beta, eps, momentum, running_mean, running_var, coeffs, n_last,
+                     1.0 / (double)bm, 1.0 / (double)n_last, 1.0 / (double)rows);
+  return launch_status();
+}
+}  // namespace gs
 
 extern "C" size_t gs_bn_stats_workspace_bytes(int64_t rows, int32_t C) {
   if (rows <= 0 || C <= 0 || (C & 3)) return 0;
@@ -572,4 +738,11 @@ extern "C" int gs_colsum(const float* src, int64_t rows, int32_t C, int32_t ld, 
                      ld, g.rows_per_block, part);
   launch_sum_partials(part, g.gx, C, out, nullptr, 0, st);
   return launch_status();
+}
+
+extern "C" int gs_debug_bn_tile_finalize(const float* part, int np, int bm, int64_t rows, int C,
+                                         float* coeffs, void* stream, int v) {
+  (void)v;
+  return bn_tile_finalize(part, np, bm, rows, C, nullptr, nullptr, 1e-5f, 0.1f, nullptr, nullptr,
+                          coeffs, as_stream(stream));
 }

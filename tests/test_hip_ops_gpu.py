@@ -326,3 +326,68 @@ def test_sgd_step_matches_torch(hip_lib):
         lib.check(hip_lib.gs_sgd_step(pg.data_ptr(), gg.data_ptr(), buf.data_ptr(), n, 0.01, 0.9,
                                       5e-4, 1.0, current_stream_ptr()), "sgd")
     assert rel_err(pg, pr) < 1e-6
+
+
+# conv -> BN (+ residual) (+ ReLU) through the one-call-per-direction entry points
+# (gs_conv_bn_forward / gs_conv_bn_backward), which also fuse the batch statistics into the conv:
+# no split-K -> per-tile partials in the conv epilogue; split-K -> slab reduction + statistics pass.
+CONV_BN_CASES = [
+    # ci  co  k  n   h   w  relu  residual     (rows, K) decide the statistics mode
+    (32, 64, 3, 2, 40, 48, True, False),      # 3840 rows, 60 tiles: split-K, fused reduce+stats
+    (64, 64, 1, 2, 121, 125, True, True),     # 30250 rows (ragged last tile), epilogue partials
+    (64, 256, 1, 2, 96, 96, False, False),    # 18432 rows x 4 column tiles: epilogue partials
+    (128, 48, 3, 1, 9, 11, True, False),      # 99 rows: tiny, ragged, split-K
+    (16, 80, 3, 2, 64, 64, True, True),       # BN = 80 tiles, two LDS column chunks
+]
+
+
+@pytest.mark.parametrize("case", CONV_BN_CASES)
+def test_conv_bn_fused_calls(hip_lib, case):
+    from gaia_seg_amd.core.bricks import DynamicBatchNorm2d, DynamicConv2d, conv_bn_act
+    from gaia_seg_amd.hip.runtime import tape_function
+    ci, co, k, n, h, w, relu, use_res = case
+    torch.manual_seed(7)
+    conv = DynamicConv2d(ci, co, k, padding=k // 2, bias=False)
+    bn = DynamicBatchNorm2d(co)
+    torch.nn.init.normal_(conv.weight, 0, 0.2)
+    torch.nn.init.uniform_(bn.weight, 0.5, 1.5)
+    torch.nn.init.normal_(bn.bias, 0, 0.3)
+    x = torch.randn(n, ci, h, w) + 0.5
+    res = torch.randn(n, co, h, w) if use_res else None
+
+    # reference: plain PyTorch on the CPU
+    w_ref = conv.weight.detach().clone().contiguous().requires_grad_(True)
+    g_ref = bn.weight.detach().clone().requires_grad_(True)
+    b_ref = bn.bias.detach().clone().requires_grad_(True)
+    x_ref = x.clone().requires_grad_(True)
+    r_ref = res.clone().requires_grad_(True) if use_res else None
+    rm, rv = torch.zeros(co), torch.ones(co)
+    y_ref = F.conv2d(x_ref, w_ref, None, 1, k // 2)
+    z_ref = F.batch_norm(y_ref, rm, rv, g_ref, b_ref, True, 0.1, 1e-5)
+    if use_res:
+        z_ref = z_ref + r_ref
+    if relu:
+        z_ref = F.relu(z_ref)
+    gz = torch.randn_like(z_ref)
+    z_ref.backward(gz)
+
+    conv, bn = conv.to(DEV), bn.to(DEV).train()
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    inputs = [xg]
+    if use_res:
+        rg = res.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        inputs.append(rg)
+
+    def run(tape, acts):
+        return [conv_bn_act(tape, conv, bn, acts[0], relu=relu,
+                            residual=acts[1] if use_res else None)]
+    z = tape_function(run, inputs, True)[0]
+    assert rel_err(z, z_ref) < 1e-4
+    assert rel_err(bn.running_mean, rm) < 1e-4 and rel_err(bn.running_var, rv) < 1e-4
+    z.backward(gz.to(DEV))
+    assert rel_err(conv.weight.grad, w_ref.grad) < 2e-4
+    assert rel_err(bn.weight.grad, g_ref.grad) < 2e-4
+    assert rel_err(bn.bias.grad, b_ref.grad) < 2e-4
+    assert rel_err(xg.grad, x_ref.grad) < 2e-4
+    if use_res:
+        assert rel_err(rg.grad, r_ref.grad) < 1e-5

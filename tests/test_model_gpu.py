@@ -29,6 +29,14 @@ def _run_pair(cfg, arch, deep_stem=False, size=(64, 96), check_grads=True):
     out["loss"].backward()
     errs, gerrs = {}, {}
     for k, v in losses_o.items():
+        if k.endswith("acc_seg"):
+            # accuracy (in percent) is a step function of the logits: a pixel whose two best logits
+            # tie to within rounding may flip between two correct fp32 implementations.  Allow two
+            # of the N*H*W pixels (same reasoning as the ReLU-mask note in conftest.l2_err).
+            npix = float(gt.numel())
+            flips = abs(float(out["log_vars"][k]) - float(v)) / 100.0 * npix
+            errs[k] = 0.0 if flips <= 2.01 else flips
+            continue
         errs[k] = abs(float(out["log_vars"][k]) - float(v)) / max(abs(float(v)), 1e-6)
     errs["loss"] = abs(float(out["loss"]) - float(loss_o)) / abs(float(loss_o))
     if check_grads:
