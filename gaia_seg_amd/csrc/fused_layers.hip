@@ -7,8 +7,8 @@
 // is of the same order as the kernels themselves: with one host call per module the host, not
 // the GPU, sets the step time for the deeper subnets.  These entry points issue the launches of a
 // conv+BN pair back to back from C (forward: conv, [split-K reduce], BN statistics, finalize,
-// apply; backward: BN reduce, BN apply, wgrad on the side stream, dgrad).  They only compose the
-// operator entry points of this library: results are bit-identical to calling those one by one.
+// apply; backward: BN reduce, BN apply, wgrad on the side stream, dgrad), and let the BatchNorm
+// batch statistics come out of the conv (epilogue partials / fused slab reduce, see norm.hip).
 #include <vector>
 #include "common.h"
 #include "fused_internal.h"

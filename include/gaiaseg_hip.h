@@ -163,9 +163,13 @@ int gs_bn_bwd_apply(const float* dy, int32_t ld_dy, const float* x, int32_t ldx,
 /* Replaces the module chain conv -> norm -> activate of gaiavision DynamicConvModule and of each
  * conv/bn pair of DynamicBottleneck (gaiaseg/models/utils/dynamic_res_layer.py:84-125,
  * gaiaseg/models/backbones/dynamic_resnet.py:255-302, decode heads' ConvModules) for rank-local
- * BatchNorm.  Pure composition of gs_conv2d_*, gs_bn_* and gs_stream_fork above: bit-identical to
- * calling them one by one; it exists because one host call per module costs as much host time as
- * the kernels cost GPU time on this path. */
+ * BatchNorm.  Same kernels as gs_conv2d_*, gs_bn_* and gs_stream_fork; it exists because one host
+ * call per module costs as much host time as the kernels cost GPU time on this path, and because
+ * the batch statistics can then come from the conv itself: without split-K the conv epilogue writes
+ * per-tile partial sums that are merged exactly (Chan et al., double, fixed order — equal to
+ * gs_bn_stats up to rounding); with split-K one kernel sums the slabs, stores y and accumulates the
+ * statistics (bit-identical to gs_conv2d_forward + gs_bn_stats_finalize).  Backward is a pure
+ * composition.  workspace must be >= gs_conv_bn_workspace_bytes(d). */
 typedef struct gs_bn_args {
   const float* gamma;        /* [>= C] or NULL (1)                                              */
   const float* beta;         /* [>= C] or NULL (0)                                              */
