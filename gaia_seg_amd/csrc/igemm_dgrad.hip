@@ -19,6 +19,18 @@ size_t gs_dgrad_strided_slab_bytes(const gs_conv_desc* d) {
   return need;
 }
 
+// dx[r][0..C) = 0 for a channel slice of a wider buffer (pixel stride ld > C)
+static __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ dx, long rows,
+                                                               int c4, long ld) {
+  const long total = rows * c4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c4;
+    const int q = (int)(i - r * c4);
+    *reinterpret_cast<f32x4*>(dx + r * ld + q * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 static int dgrad_strided_fast(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
                               int accumulate, void* workspace, size_t workspace_bytes,
                               hipStream_t st) {
@@ -32,13 +44,16 @@ static int dgrad_strided_fast(const gs_conv_desc* d, const float* dy, const floa
   if (!accumulate && any_empty) {
     // classes without taps (e.g. 3 of the 4 classes of a 1x1 stride-2 conv) stay zero.  A dense dx is
     // cleared with the 1-D memset (a fill kernel); hipMemset2DAsync is staged through ~30 buffer
-    // copies per call on ROCm 7.2 (seen in the r01 trace) and is kept for sliced dx only.
+    // copies per call on ROCm 7.2 (seen in the r01 trace), so a sliced dx gets its own fill kernel.
     const size_t rows = (size_t)d->N * d->H * d->W;
-    hipError_t e = (d->x_sw == d->Ci)
-                       ? hipMemsetAsync(dx, 0, rows * d->Ci * sizeof(float), st)
-                       : hipMemset2DAsync(dx, (size_t)d->x_sw * sizeof(float), 0,
-                                          (size_t)d->Ci * sizeof(float), rows, st);
-    if (e != hipSuccess) return static_cast<int>(e);
+    if (d->x_sw == d->Ci) {
+      hipError_t e = hipMemsetAsync(dx, 0, rows * d->Ci * sizeof(float), st);
+      if (e != hipSuccess) return static_cast<int>(e);
+    } else {
+      const long quads = (long)rows * (d->Ci / 4);
+      hipLaunchKernelGGL(zero_rows_kernel, dim3(stream_grid(quads, 256)), dim3(256), 0, st, dx,
+                         (long)rows, d->Ci / 4, (long)d->x_sw);
+    }
   }
   for (int ph = 0; ph < s; ++ph)
     for (int pw = 0; pw < s; ++pw) {

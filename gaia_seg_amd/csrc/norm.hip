@@ -739,10 +739,3 @@ extern "C" int gs_colsum(const float* src, int64_t rows, int32_t C, int32_t ld, 
   launch_sum_partials(part, g.gx, C, out, nullptr, 0, st);
   return launch_status();
 }
-
-extern "C" int gs_debug_bn_tile_finalize(const float* part, int np, int bm, int64_t rows, int C,
-                                         float* coeffs, void* stream, int v) {
-  (void)v;
-  return bn_tile_finalize(part, np, bm, rows, C, nullptr, nullptr, 1e-5f, 0.1f, nullptr, nullptr,
-                          coeffs, as_stream(stream));
-}

@@ -209,6 +209,10 @@ class _TapeFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, need_tape, anchor, *inputs):
         # (grad mode is always off inside Function.forward: the caller decides need_tape)
+        # outputs nobody consumes (e.g. the stage-1/2 feature maps under an FCN head) must arrive as
+        # None in backward, not as materialised zero tensors that would be filled, copied into NHWC
+        # and added to the real gradients (150 us per step in the r01 trace)
+        ctx.set_materialize_grads(False)
         tape = Tape(enabled=need_tape)
         acts_in = [Act.from_nchw(t) for t in inputs]
         outs = runner(tape, acts_in)
