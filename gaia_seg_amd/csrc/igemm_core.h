@@ -464,15 +464,19 @@ __device__ __forceinline__ void pipelined_k_loop(int nk, float* lds,
         if (g < 3 && q == Q_RB) read_b(bc, g + 1, fb[nxt]);
         if (g == 0 && q == Q_LA) load_a(rla);
         if (g == 0 && q == Q_LB) load_b(rlb);
-        if (g == 2 && q == Q_LA) store_a(rsa, bn);
-        if (g == 2 && q == Q_LB) store_b(rsb, bn + T::A_SZ);
+        if (g == 1 && q == Q_LA) store_a(rsa, bn);
+        if (g == 1 && q == Q_LB) store_b(rsb, bn + T::A_SZ);
+        // The step's only barrier sits at the end of k-group 2: by then every wave has read all of
+        // the current stage (group 3's fragments were fetched at the start of group 2) and has
+        // stored its share of the next one (group 1), so the barrier both frees the current buffer
+        // for the stores of the step after next and publishes the next stage -- whose first
+        // fragments are then fetched behind the MFMAs of group 3 instead of after the step.
+        if (g == 2 && q == NQ - 1) __syncthreads();
+        if (g == 3 && q == 0) read_a(bn, 0, fa[0]);
+        if (g == 3 && q == Q_RB) read_b(bn, 0, fb[0]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
-    read_a(bn, 0, fa[0]);
-    read_b(bn, 0, fb[0]);
-    __builtin_amdgcn_sched_barrier(0);
   };
   if (nk <= 0) return;
   load_a(ra0); load_b(rb0);

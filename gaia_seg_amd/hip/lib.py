@@ -132,9 +132,11 @@ def build(verbose=False, jobs=None):
 
 def load():
     """Load the shared object, bind every prototype, check the ABI version. Raises on any gap."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    if os.environ.get("GS_HIP_LIB"):   # A/B of two builds of the same library (tuning only)
+        LIB_PATH = os.environ["GS_HIP_LIB"]
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             "%s not found: the HIP extension is required (no CPU fallback). Build it with "
