@@ -391,3 +391,63 @@ def test_conv_bn_fused_calls(hip_lib, case):
     assert rel_err(xg.grad, x_ref.grad) < 2e-4
     if use_res:
         assert rel_err(rg.grad, r_ref.grad) < 1e-5
+
+
+def test_conv_bn_eval_mode_and_frozen_params(hip_lib):
+    """Fused conv+BN entry with running statistics (norm_eval) and with frozen conv / BN parameters:
+    no statistics update, no gradient for frozen tensors, input gradient still correct."""
+    from gaia_seg_amd.core.bricks import DynamicBatchNorm2d, DynamicConv2d, conv_bn_act
+    from gaia_seg_amd.hip.runtime import tape_function
+    torch.manual_seed(3)
+    ci, co, n, h, w = 32, 48, 2, 20, 24
+    conv = DynamicConv2d(ci, co, 3, padding=1, bias=False)
+    bn = DynamicBatchNorm2d(co)
+    torch.nn.init.normal_(conv.weight, 0, 0.2)
+    bn.running_mean.normal_(0, 0.5)
+    bn.running_var.uniform_(0.5, 2.0)
+    torch.nn.init.uniform_(bn.weight, 0.5, 1.5)
+    torch.nn.init.normal_(bn.bias, 0, 0.3)
+    x = torch.randn(n, ci, h, w)
+    x_ref = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(x_ref, conv.weight.detach(), None, 1, 1)
+    z_ref = F.relu(F.batch_norm(y_ref, bn.running_mean.clone(), bn.running_var.clone(),
+                                bn.weight.detach(), bn.bias.detach(), False, 0.1, 1e-5))
+    gz = torch.randn_like(z_ref)
+    z_ref.backward(gz)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+
+    conv, bn = conv.to(DEV), bn.to(DEV).eval()
+    for p in list(conv.parameters()) + list(bn.parameters()):
+        p.requires_grad_(False)
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    z = tape_function(lambda tape, acts: [conv_bn_act(tape, conv, bn, acts[0], relu=True)], [xg], True)[0]
+    assert rel_err(z, z_ref) < 1e-4
+    z.backward(gz.to(DEV))
+    assert rel_err(xg.grad, x_ref.grad) < 2e-4
+    assert conv.weight.grad is None and bn.weight.grad is None and bn.bias.grad is None
+    assert torch.equal(bn.running_mean.cpu(), rm0) and torch.equal(bn.running_var.cpu(), rv0)
+
+
+def test_conv_bn_fused_equals_module_by_module(hip_lib, monkeypatch):
+    """The one-call path and the module-by-module path launch the same kernels except for where the
+    batch statistics are accumulated: outputs agree to rounding, split-K shapes bit for bit."""
+    from gaia_seg_amd.core.bricks import DynamicBatchNorm2d, DynamicConv2d, conv_bn_act
+    from gaia_seg_amd.hip.runtime import Act, Tape
+    torch.manual_seed(11)
+    for (ci, co, k, n, h, w, exact) in [(64, 64, 3, 2, 24, 32, True), (32, 128, 1, 2, 96, 128, False)]:
+        conv = DynamicConv2d(ci, co, k, padding=k // 2, bias=False).to(DEV)
+        bn = DynamicBatchNorm2d(co).to(DEV).train()
+        x = Act(torch.randn(n, h, w, ci, device=DEV), True)
+        outs = []
+        for fused in (True, False):
+            if fused:
+                monkeypatch.delenv("GS_NO_FUSED_CALLS", raising=False)
+            else:
+                monkeypatch.setenv("GS_NO_FUSED_CALLS", "1")
+            bn.running_mean.zero_()
+            bn.running_var.fill_(1.0)
+            outs.append(conv_bn_act(Tape(enabled=False), conv, bn, x, relu=True).t.clone())
+        if exact:   # 1536 rows -> 24 tiles: split-K, fused reduce+stats is bit-identical
+            assert torch.equal(outs[0], outs[1])
+        else:
+            assert rel_err(outs[0], outs[1]) < 1e-5
