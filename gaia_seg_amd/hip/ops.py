@@ -32,7 +32,7 @@ def _side_stream(dev):
     key = (dev.type, dev.index)
     s = _side_streams.get(key)
     if s is None:
-        s = torch.cuda.Stream(device=dev)
+        s = torch.cuda.Stream(device=dev)   # (stream priorities made no difference, r01 A/B)
         _side_streams[key] = s
     return s
 
