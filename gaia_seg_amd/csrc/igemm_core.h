@@ -92,6 +92,8 @@ struct Tile {
   static constexpr int C_SZ = BM * PC;
   // (+512 floats behind the C image: scratch of the epilogue's per-tile BatchNorm partial sums)
   static constexpr int LDSF = (2 * STAGE > C_SZ + 512) ? 2 * STAGE : C_SZ + 512;
+  // four stages for the paired K loop (two K steps per barrier)
+  static constexpr int LDSF2 = (4 * STAGE > C_SZ + 512) ? 4 * STAGE : C_SZ + 512;
   static constexpr int WM = BM / 4;   // rows per wave
   static constexpr int TM = WM / 16;  // 16x16 tiles per wave along M
   static constexpr int TN = BN / 16;
@@ -496,6 +498,93 @@ __device__ __forceinline__ void pipelined_k_loop(int nk, float* lds,
   }
 }
 
+
+// Paired variant: TWO K steps per barrier (four LDS stages, four register sets).  With 64-row tiles
+// a K step is only 512 MFMA cycles per wave, and the per-step barrier (+ what cannot be hidden
+// around it) costs a third of that: the MFMA pipe was 62-64 % busy over whole launches of the
+// 64x64 kernels against ~82 % for the 128x128 ones (r01 SQ counters).  Phase p computes the pair
+// (2p, 2p+1) from buffers C0/C1, stores pair p+1 (loaded during phase p-1) into N0/N1 and issues
+// the global loads of pair p+2.  The barrier sits at the end of k-group 6 of 8: all reads of the
+// current pair are complete by then (group 7's fragments are fetched at the start of group 6) and
+// the next pair is stored; group 7 runs behind it while the next pair's first fragments arrive.
+// An odd K-step count pads the last pair with a zero step (bounds-checked loads return zeros).
+template <int BM, int BN, int AS, class LA, class LB, class SA, class SB>
+__device__ __forceinline__ void pipelined_k_loop_pairs(
+    int nk, float* lds, f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN], int wave, int lane,
+    LA&& load_a, LB&& load_b, SA&& store_a, SB&& store_b) {
+  using T = Tile<BM, BN>;
+  constexpr int NQ = T::TM * T::TN;
+  const int kk = lane >> 4, li = lane & 15;
+  const int a_base = kk * T::PA + wave * T::WM + li;
+  const int b_base = T::A_SZ + kk * T::PB + li;
+  float fa[2][T::TM], fb[2][T::TN];
+  auto read_a = [&](const float* buf, int g, float (&a)[T::TM]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) a[i] = buf[a_base + g * (4 * T::PA + 8) + i * 16];
+  };
+  auto read_b = [&](const float* buf, int g, float (&b)[T::TN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) b[j] = buf[b_base + g * (4 * T::PB + 8) + j * 16];
+  };
+  constexpr int Q_RB = NQ > 1 ? 1 : 0, Q_LA = NQ > 2 ? 2 : NQ - 1, Q_LB = NQ > 4 ? 4 : NQ - 1;
+  f32x4 ra0[AS], ra1[AS], ra2[AS], ra3[AS];
+  f32x4 rb0[T::BV], rb1[T::BV], rb2[T::BV], rb3[T::BV];
+  float* A0 = lds;
+  float* A1 = lds + T::STAGE;
+  float* B0 = lds + 2 * T::STAGE;
+  float* B1 = lds + 3 * T::STAGE;
+  // rl*: sets refilled with pair p+2; rs*: sets holding pair p+1, stored this phase
+  auto phase = [&](f32x4 (&rla0)[AS], f32x4 (&rlb0)[T::BV], f32x4 (&rla1)[AS], f32x4 (&rlb1)[T::BV],
+                   const f32x4 (&rsa0)[AS], const f32x4 (&rsb0)[T::BV], const f32x4 (&rsa1)[AS],
+                   const f32x4 (&rsb1)[T::BV], const float* c0, const float* c1, float* n0,
+                   float* n1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int G = 0; G < 8; ++G) {
+      const int cur = G & 1, nxt = cur ^ 1;
+      const float* cb = G < 4 ? c0 : c1;                 // buffer of this k-group
+      const float* nb = (G + 1) < 4 ? c0 : c1;           // buffer of the next k-group (G < 7)
+      const int gn = (G + 1) & 3;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int i = q / T::TN, j = q - i * T::TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+        if (G < 7 && q == 0) read_a(nb, gn, fa[nxt]);
+        if (G < 7 && q == Q_RB) read_b(nb, gn, fb[nxt]);
+        if (G == 0 && q == Q_LA) load_a(rla0);
+        if (G == 0 && q == Q_LB) load_b(rlb0);
+        if (G == 1 && q == Q_LA) load_a(rla1);
+        if (G == 1 && q == Q_LB) load_b(rlb1);
+        if (G == 2 && q == Q_LA) store_a(rsa0, n0);
+        if (G == 2 && q == Q_LB) store_b(rsb0, n0 + T::A_SZ);
+        if (G == 4 && q == Q_LA) store_a(rsa1, n1);
+        if (G == 4 && q == Q_LB) store_b(rsb1, n1 + T::A_SZ);
+        if (G == 6 && q == NQ - 1) __syncthreads();
+        if (G == 7 && q == 0) read_a(n0, 0, fa[0]);
+        if (G == 7 && q == Q_RB) read_b(n0, 0, fb[0]);
+        (void)cb;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  if (nk <= 0) return;
+  const int npairs = (nk + 1) >> 1;
+  load_a(ra0); load_b(rb0);
+  load_a(ra1); load_b(rb1);
+  load_a(ra2); load_b(rb2);
+  load_a(ra3); load_b(rb3);
+  store_a(ra0, A0); store_b(rb0, A0 + T::A_SZ);
+  store_a(ra1, A1); store_b(rb1, A1 + T::A_SZ);
+  __syncthreads();
+  read_a(A0, 0, fa[0]);
+  read_b(A0, 0, fb[0]);
+  for (int pp = 0; pp < npairs; pp += 2) {
+    // phase pp: pair in A, next pair (held in sets 2,3) -> B, refill sets 0,1
+    phase(ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3, A0, A1, B0, B1);
+    // phase pp+1: pair in B, next pair (sets 0,1) -> A, refill sets 2,3
+    if (pp + 1 < npairs) phase(ra2, rb2, ra3, rb3, ra0, rb0, ra1, rb1, B0, B1, A0, A1);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fast path of forward / stride-1 dgrad for the shapes that carry the FLOPs: NHWC source,
 // channels per tap a multiple of BK (every width of the search space is a multiple of 16), 1x1 or
@@ -518,10 +607,11 @@ __device__ __forceinline__ unsigned long long gs_stamp() {
 }
 // ROLE only names the instantiation (gs_conv_desc::role): role 1 = the bottleneck conv2 (K3), so
 // that rocprofv3 attributes the headline kernel separately from the other 3x3 convolutions.
-template <int BM, int BN, bool BTRANS, int KS, int ABL = 0, int ROLE = 0, bool PIPE = true>
+template <int BM, int BN, bool BTRANS, int KS, int ABL = 0, int ROLE = 0, bool PIPE = true,
+          bool PAIR = false>
 __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
-  __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
+  __shared__ __attribute__((aligned(16))) float lds[PAIR ? T::LDSF2 : T::LDSF];
   constexpr int AS = BM / 64;
   constexpr int MAXTAPS = KS * KS;  // KS only bounds the tap loop and tags the kernel name
   const int ntaps = p.kh_n * p.kw_n;
@@ -738,6 +828,12 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
       }
     };
     GS_STAMP(st_l0)
+    if constexpr (PAIR)
+      pipelined_k_loop_pairs<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
+    else
+      if constexpr (PAIR)
+    pipelined_k_loop_pairs<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
+  else
     pipelined_k_loop<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
   } else {
   // step i computes from buf[i&1]; two register sets hold steps i+1 and i+2 (in flight); the set
@@ -944,10 +1040,10 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_kernel(const IgemmArgs p) {
 // index math hoisted / incremental, bounds-checked buffer loads (no branches), and THREE K steps
 // of global loads in flight (three register sets, statically rotated).
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int KS>
+template <int BM, int BN, int KS, bool PAIR = false>
 __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
-  __shared__ __attribute__((aligned(16))) float lds[T::LDSF];
+  __shared__ __attribute__((aligned(16))) float lds[PAIR ? T::LDSF2 : T::LDSF];
   constexpr int QA = BM / 4;
   constexpr int AS = BK * QA / NT;  // 1 (BM = 64) or 2 (BM = 128)
   constexpr int KSTR = NT / QA;
@@ -1063,7 +1159,10 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
       }
     }
   };
-  pipelined_k_loop<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
+  if constexpr (PAIR)
+    pipelined_k_loop_pairs<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
+  else
+    pipelined_k_loop<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
 
   float* Cs = lds;
   constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
@@ -1157,6 +1256,7 @@ static int env_int(const char* name, int dflt) {
 static bool wg_target_forced() { static const bool v = getenv("GS_WG_TARGET") != nullptr; return v; }
 static int wg_target() { static const int v = env_int("GS_WG_TARGET", 2 * kNumCU); return v; }
 static int dyn_lds() { static const int v = env_int("GS_DYN_LDS", 0); return v; }
+static int pair_min_ksteps() { static const int v = env_int("GS_PAIR_MIN", 16); return v; }
 static int min_ksteps() { static const int v = env_int("GS_MIN_KSTEPS", 4); return v; }
 
 extern int g_force_plan[3];  // capi_misc.hip: {bm, bn, splits} set by gs_debug_force_plan (0 = off)
@@ -1279,9 +1379,18 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
     a.tile_order = force >= 0 ? force : (b_bytes > a_bytes ? 1 : 0);
   }
   const dim3 grid(pl.tiles_m * pl.tiles_n * pl.splits), block(NT);
+  // long K ranges run two K steps per barrier (pipelined_k_loop_pairs) when the launch has at most
+  // three workgroups per CU anyway (its four LDS stages allow no more); big grids and short K
+  // ranges keep the two-stage loop, whose smaller footprint lets five workgroups per CU overlap
+  // their fill / drain (r01 A/B: s2..s4 3x3 and the head convs +3..7 %, s1 3x3 -3 % if paired)
+  const bool pair = pl.nk_per_split >= pair_min_ksteps() &&
+                    (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
 #define GS_FAST(BM_, BN_)                                                                  \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                      \
-    hipLaunchKernelGGL((igemm_rows_fast_kernel<BM_, BN_, BTRANS, KS, 0, ROLE>), grid, block, dyn_lds(), st, a); \
+    if (pair)                                                                              \
+      hipLaunchKernelGGL((igemm_rows_fast_kernel<BM_, BN_, BTRANS, KS, 0, ROLE, true, true>), grid, block, dyn_lds(), st, a); \
+    else                                                                                   \
+      hipLaunchKernelGGL((igemm_rows_fast_kernel<BM_, BN_, BTRANS, KS, 0, ROLE>), grid, block, dyn_lds(), st, a); \
     return;                                                                                \
   }
   GS_FAST(128, 128) GS_FAST(128, 96) GS_FAST(128, 80) GS_FAST(128, 64) GS_FAST(128, 48) GS_FAST(128, 32)
@@ -1300,9 +1409,14 @@ static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t
   IgemmArgs a = a_in;
   a.nsplits = pl.splits;
   const dim3 grid(pl.tiles_m * pl.tiles_n * pl.splits), block(NT);
+  const bool pair = pl.nk_per_split >= pair_min_ksteps() &&
+                    (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
 #define GS_WGF(BM_, BN_)                                                                  \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                     \
-    hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS>), grid, block, dyn_lds(), st, a);   \
+    if (pair)                                                                             \
+      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS, true>), grid, block, dyn_lds(), st, a); \
+    else                                                                                  \
+      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS>), grid, block, dyn_lds(), st, a);   \
     return;                                                                               \
   }
   GS_WGF(128, 128) GS_WGF(128, 96) GS_WGF(128, 80) GS_WGF(128, 64) GS_WGF(128, 48) GS_WGF(128, 32)
