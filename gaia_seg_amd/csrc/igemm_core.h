@@ -488,14 +488,20 @@ __device__ __forceinline__ void pipelined_k_loop(int nk, float* lds,
   __syncthreads();
   read_a(buf0, 0, fa[0]);
   read_b(buf0, 0, fb[0]);
-  for (int ib = 0; ib < nk; ib += 6) {
-    if (ib + 0 < nk) phase(ra0, rb0, ra1, rb1, buf0, buf1);
-    if (ib + 1 < nk) phase(ra1, rb1, ra2, rb2, buf1, buf0);
-    if (ib + 2 < nk) phase(ra2, rb2, ra0, rb0, buf0, buf1);
-    if (ib + 3 < nk) phase(ra0, rb0, ra1, rb1, buf1, buf0);
-    if (ib + 4 < nk) phase(ra1, rb1, ra2, rb2, buf0, buf1);
-    if (ib + 5 < nk) phase(ra2, rb2, ra0, rb0, buf1, buf0);
+  int ib = 0;
+  for (; ib + 6 <= nk; ib += 6) {   // unconditional body (see pipelined_k_loop_pairs)
+    phase(ra0, rb0, ra1, rb1, buf0, buf1);
+    phase(ra1, rb1, ra2, rb2, buf1, buf0);
+    phase(ra2, rb2, ra0, rb0, buf0, buf1);
+    phase(ra0, rb0, ra1, rb1, buf1, buf0);
+    phase(ra1, rb1, ra2, rb2, buf0, buf1);
+    phase(ra2, rb2, ra0, rb0, buf1, buf0);
   }
+  if (ib + 0 < nk) phase(ra0, rb0, ra1, rb1, buf0, buf1);
+  if (ib + 1 < nk) phase(ra1, rb1, ra2, rb2, buf1, buf0);
+  if (ib + 2 < nk) phase(ra2, rb2, ra0, rb0, buf0, buf1);
+  if (ib + 3 < nk) phase(ra0, rb0, ra1, rb1, buf1, buf0);
+  if (ib + 4 < nk) phase(ra1, rb1, ra2, rb2, buf0, buf1);
 }
 
 
@@ -577,12 +583,17 @@ __device__ __forceinline__ void pipelined_k_loop_pairs(
   __syncthreads();
   read_a(A0, 0, fa[0]);
   read_b(A0, 0, fb[0]);
-  for (int pp = 0; pp < npairs; pp += 2) {
-    // phase pp: pair in A, next pair (held in sets 2,3) -> B, refill sets 0,1
+  // (the loop body is unconditional: a conditional second phase made the compiler rotate the
+  // accumulators through VGPRs at every iteration -- accvgpr reads that wait for the MFMA pipe to
+  // drain, r01 ISA; the odd pair is peeled off instead)
+  int pp = 0;
+  for (; pp + 1 < npairs; pp += 2) {
+    // pair in A, next pair (held in sets 2,3) -> B, refill sets 0,1
     phase(ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3, A0, A1, B0, B1);
-    // phase pp+1: pair in B, next pair (sets 0,1) -> A, refill sets 2,3
-    if (pp + 1 < npairs) phase(ra2, rb2, ra3, rb3, ra0, rb0, ra1, rb1, B0, B1, A0, A1);
+    // pair in B, next pair (sets 0,1) -> A, refill sets 2,3
+    phase(ra2, rb2, ra3, rb3, ra0, rb0, ra1, rb1, B0, B1, A0, A1);
   }
+  if (pp < npairs) phase(ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3, A0, A1, B0, B1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -762,7 +773,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     // scalar K-step state of the NEXT stage to load (no divisions in the loop)
     const int a_step_h = 4 * p.step_h * (int)p.s_h, a_step_w = 4 * p.step_w * (int)p.s_w;
     const int b_step_h = 4 * (int)p.d_tap_h, b_step_w = 4 * (int)p.d_tap_w;
-    const int b_cstep = BTRANS ? 4 * BK : 4 * BK * p.d_row;
+    const int b_cmul = BTRANS ? 4 : 4 * p.d_row;
     int kh = tap / p.kw_n, kw = tap - kh * p.kw_n;
     int aoff = kh * a_step_h + kw * a_step_w + 4 * c0;
     int bbase = kh * b_step_h + kw * b_step_w + (BTRANS ? 4 * c0 : 4 * c0 * p.d_row);
@@ -788,18 +799,20 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
         else
           rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dense, off, 0, 0));
       }
-      // advance to the following K step
+      // advance to the following K step: pure integer arithmetic, the offsets are recomputed from
+      // (kh, kw, c0) every time -- written as selects this became four scalar branches per K step
+      // inside the MFMA stream (r01 ISA)
       --k_left;
       const int nc0 = c0 + BK;
-      const bool wrap = nc0 >= p.Cs;          // next K step starts a new tap
-      const int nkw = kw + 1;
-      const bool wrapw = nkw >= p.kw_n;
-      kh += (wrap && wrapw) ? 1 : 0;
-      kw = wrap ? (wrapw ? 0 : nkw) : kw;
-      c0 = wrap ? 0 : nc0;
-      tapbit = wrap ? (tapbit << 1) : tapbit;
-      aoff = wrap ? kh * a_step_h + kw * a_step_w : aoff + 4 * BK;
-      bbase = wrap ? kh * b_step_h + kw * b_step_w : bbase + b_cstep;
+      const int wrap = nc0 >= p.Cs ? 1 : 0;          // next K step starts a new tap
+      const int nkw = kw + wrap;
+      const int wrapw = nkw >= p.kw_n ? 1 : 0;
+      kh += wrapw;
+      kw = nkw * (1 - wrapw);
+      c0 = nc0 * (1 - wrap);
+      tapbit <<= wrap;
+      aoff = kh * a_step_h + kw * a_step_w + 4 * c0;
+      bbase = kh * b_step_h + kw * b_step_w + c0 * b_cmul;
     };
     auto store_a = [&](const f32x4 (&ra)[AS], float* As) __attribute__((always_inline)) {
       if constexpr (ABL >= 2 && ABL != 9) { asm volatile("" ::"v"(ra[0][0])); return; }
