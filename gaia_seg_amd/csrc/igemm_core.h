@@ -770,13 +770,16 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
 #define GS_STAMP(x) if constexpr (ABL == 9) { x = gs_stamp(); }
   if constexpr (ABL == 9) st_k0 = __builtin_amdgcn_s_memrealtime();
   if constexpr (PIPE) {
-    // scalar K-step state of the NEXT stage to load (no divisions in the loop)
+    // scalar K-step state of the NEXT stage to load (no divisions, no branches in the loop).
+    // (An incremental form with precomputed deltas saves ~10 SALU per K step but pushed the kernel
+    // past its SGPR budget: the buffer descriptors were spilled to VGPRs and every load became a
+    // waterfall loop.  The kernel sits at 103 SGPRs; keep the live scalar set small.)
     const int a_step_h = 4 * p.step_h * (int)p.s_h, a_step_w = 4 * p.step_w * (int)p.s_w;
     const int b_step_h = 4 * (int)p.d_tap_h, b_step_w = 4 * (int)p.d_tap_w;
     const int b_cmul = BTRANS ? 4 : 4 * p.d_row;
     int kh = tap / p.kw_n, kw = tap - kh * p.kw_n;
     int aoff = kh * a_step_h + kw * a_step_w + 4 * c0;
-    int bbase = kh * b_step_h + kw * b_step_w + (BTRANS ? 4 * c0 : 4 * c0 * p.d_row);
+    int bbase = kh * b_step_h + kw * b_step_w + c0 * b_cmul;
     unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
     int k_left = nk;
     auto load_a = [&](f32x4 (&ra)[AS]) __attribute__((always_inline)) {
@@ -844,10 +847,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     if constexpr (PAIR)
       pipelined_k_loop_pairs<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
     else
-      if constexpr (PAIR)
-    pipelined_k_loop_pairs<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
-  else
-    pipelined_k_loop<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
+      pipelined_k_loop<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
   } else {
   // step i computes from buf[i&1]; two register sets hold steps i+1 and i+2 (in flight); the set
   // freed at step i is refilled with step i+3.  Unrolled by 6: buffer parity and set index static.
