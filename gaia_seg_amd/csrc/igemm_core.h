@@ -19,6 +19,7 @@
 // stores and the MFMA fragment reads (lane l reads [k = l>>4][i = l&15]) are bank-conflict free.
 #pragma once
 #include <algorithm>
+#include <unordered_map>
 #include "common.h"
 
 namespace gs {
@@ -1288,37 +1289,49 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
     return pl;
   }
   if (pipelined && !wg_target_forced() && env_int("GS_FORCE_BM", 0) == 0) {
-    // Row kernels (forward / dgrad), software-pipelined K loop.  Fitted to the r01 plan sweep
-    // (tools/sweep_conv_plans.py over the supernet's 1x1 / 3x3 shapes at 1024x512, bs 2;
-    // profiles/r01_plan_sweep.json): with the side work hidden behind the MFMAs a 64x64 tile runs
-    // as fast per FLOP as 128x128, and four times as many tiles mean far fewer (or no) split-K
-    // slabs to write and re-read -- s2 3x3 128: 63.8 -> 48.6 us, s4 3x3 640: 116 -> 72.6 us,
-    // s3 1x1 192->768: 33.4 -> 17.1 us.  Rule: 64-row tiles; the least padded column width of
-    // {80, 64, 48, 32} (larger on ties); split K only to reach ~2.5 workgroups per CU (row
-    // kernels) or ~4 per CU (wgrad, whose K = pixels is long and whose outputs are small).
+    // Pipelined kernels (rows and wgrad): 64-row tiles and a small cost model over the column
+    // width {80,64,48,32} and the split factor, fitted to the r01 plan sweeps
+    // (tools/sweep_conv_plans.py over the supernet's GEMM shapes at 1024x512 bs 2,
+    // profiles/r01_plan_sweep*.json).  In units of one K step of a 64x64 tile:
+    //   cost = rounds * (ksteps_per_wg + 4) * (bn/64) * width_eff * occupancy_eff  +  slab
+    // with rounds = ceil(workgroups / 256 CUs) -- the quantisation matters: 640 workgroups take as
+    // long as 768 --, occupancy_eff = 1.2 / 1.08 / 1 at 1 / 2 / >=3 rounds (fill and drain
+    // overlap only across co-resident workgroups), and slab = (2s+1) * M * N * 1.4e-6 for the
+    // split-K partials that are written and re-read.  Against the nearest-to-2.5-WGs/CU rule this
+    // model is 10 % (forward), 4 % (dgrad) and 5 % (wgrad) faster over the sweep and within 1.5 %
+    // of the per-shape optimum.  Plans are cached per shape (the search is ~2k evaluations).
+    struct Key { int M, N, K, ms; bool operator==(const Key& o) const { return M == o.M && N == o.N && K == o.K && ms == o.ms; } };
+    struct KeyHash { size_t operator()(const Key& k) const { return ((size_t)k.M * 1000003u) ^ ((size_t)k.N << 20) ^ ((size_t)k.K * 7919u) ^ (size_t)k.ms; } };
+    static thread_local std::unordered_map<Key, Plan, KeyHash> cache;
+    const Key key{M, Nn, Ktot, allow_split ? max_splits : 1};
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
     static const int kBNp[4] = {80, 64, 48, 32};
-    int best = 32, best_pad = 1 << 30;
-    for (int i = 0; i < 4; ++i) {
-      const int pad = (int)ceil_div(Nn, kBNp[i]) * kBNp[i];
-      if (pad < best_pad) { best_pad = pad; best = kBNp[i]; }
-    }
-    pl.bn = best;
+    static const double kEff[4] = {1.03, 1.0, 1.05, 1.2};
     pl.bm = 64;
-    pl.tiles_m = (int)ceil_div(M, pl.bm);
-    pl.tiles_n = (int)ceil_div(Nn, pl.bn);
+    pl.tiles_m = (int)ceil_div(M, 64);
     pl.nk_total = (int)ceil_div(Ktot, BK);
-    const long tiles = (long)pl.tiles_m * pl.tiles_n;
-    const double want = wg_per_cu * kNumCU / (double)tiles;
-    int splits = 1;
-    if (allow_split && want > 1.0) {
-      const int lo = std::max(1, (int)want), hi = lo + 1;
-      splits = (want / lo <= hi / want) ? lo : hi;   // nearest in ratio
-      const int max_by_k = std::max(1, pl.nk_total / min_ksteps());
-      splits = std::min(splits, std::min(max_by_k, max_splits));
-      while (splits > 1 && (size_t)splits * M * Nn * sizeof(float) > kMaxSlabBytes) --splits;
+    const int s_max = allow_split ? std::max(1, std::min(max_splits, pl.nk_total / min_ksteps())) : 1;
+    double best_cost = 1e300;
+    int best_bn = 64, best_s = 1;
+    for (int i = 0; i < 4; ++i) {
+      const int bn = kBNp[i];
+      const long tiles = (long)pl.tiles_m * ceil_div(Nn, bn);
+      for (int sp = 1; sp <= s_max; ++sp) {
+        if (sp > 1 && (size_t)sp * M * Nn * sizeof(float) > kMaxSlabBytes) break;
+        const long rounds = ceil_div(tiles * sp, kNumCU);
+        const double occ = rounds == 1 ? 1.2 : (rounds == 2 ? 1.08 : 1.0);
+        double cost = (double)rounds * ((double)ceil_div(pl.nk_total, sp) + 4.0) * (bn / 64.0) *
+                      kEff[i] * occ;
+        if (sp > 1) cost += (2.0 * sp + 1.0) * (double)M * (double)Nn * 1.4e-6;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best_bn = bn; best_s = sp; }
+      }
     }
-    pl.nk_per_split = (int)ceil_div(pl.nk_total, splits);
+    pl.bn = best_bn;
+    pl.tiles_n = (int)ceil_div(Nn, pl.bn);
+    pl.nk_per_split = (int)ceil_div(pl.nk_total, best_s);
     pl.splits = (int)ceil_div(pl.nk_total, pl.nk_per_split);
+    cache.emplace(key, pl);
     return pl;
   }
   // BN: least padded width, larger tile on ties
