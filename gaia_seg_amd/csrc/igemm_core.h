@@ -19,6 +19,7 @@
 // stores and the MFMA fragment reads (lane l reads [k = l>>4][i = l&15]) are bank-conflict free.
 #pragma once
 #include <algorithm>
+#include <cstdio>
 #include <unordered_map>
 #include "common.h"
 
@@ -1331,6 +1332,8 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
     pl.tiles_n = (int)ceil_div(Nn, pl.bn);
     pl.nk_per_split = (int)ceil_div(pl.nk_total, best_s);
     pl.splits = (int)ceil_div(pl.nk_total, pl.nk_per_split);
+    static const int dbg = env_int("GS_PLAN_DEBUG", 0);
+    if (dbg) fprintf(stderr, "[gs plan] M=%d N=%d K=%d max_splits=%d -> 64x%d splits %d (ksteps %d)\n", M, Nn, Ktot, key.ms, pl.bn, pl.splits, pl.nk_per_split);
     cache.emplace(key, pl);
     return pl;
   }
