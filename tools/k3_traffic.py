@@ -19,7 +19,7 @@ def collect(path, counter):
             continue
         name = r["Kernel_Name"]
         v = float(r["Counter_Value"])
-        if "igemm_rows_fast_kernel" in name and ", 0, 1, true>" in name:
+        if "igemm_rows_fast_kernel" in name and ", 0, 1, true, " in name:
             conv += v
             n_conv += 1
         elif "splitk_reduce_kernel<false, 1>" in name:
@@ -35,7 +35,7 @@ def main():
     assert n1 == n2 and n1 > 0, (n1, n2)
     per = lambda v: v * 1024.0 / n1
     res = {
-        "kernel": "igemm_rows_fast_kernel<64,BN,false,3,0,1,true> + splitk_reduce_kernel<false,1> "
+        "kernel": "igemm_rows_fast_kernel<64,BN,false,3,0,1,true,PAIR> + splitk_reduce_kernel<false,1> "
                   "(bottleneck conv2 forward of the R50 anchor, bs 2, 512x1024)",
         "k3_launches": n1, "reduce_launches": nr1,
         "conv_fetch_bytes_per_launch": round(2 * per(fc)), "conv_write_bytes_per_launch": round(per(wc)),
