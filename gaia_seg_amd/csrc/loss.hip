@@ -195,6 +195,117 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const CeArgs a, const float
   for (int c = a.d.Cls + threadIdx.x; c < ld_d; c += 256) orow[c] = 0.f;
 }
 
+
+// ---- tile form of the backward for power-of-two integer up-scaling (align_corners = false) ----
+// The gather form above evaluates every (full-resolution pixel, class) softmax term once per
+// neighbouring low-resolution pixel, i.e. four times.  For an integer scale s the full-resolution
+// pixels Y with floor((2Y+1+s)/(2s)) == ty all interpolate between low-resolution rows ty-1 and ty
+// (clamped at the borders), so one workgroup per (ty, tx) tile evaluates each term ONCE and splits
+// it over its four corners; a second kernel adds, for every low-resolution pixel, the four corner
+// sums of its four adjacent tiles in a fixed order (bit-reproducible, no atomics).  Power-of-two
+// scales keep the fp32 source coordinates exact, so the tile membership is exact too.
+constexpr int TCH = 20;   // classes per pass (19 Cityscapes classes + pad)
+__global__ __launch_bounds__(256) void ce_bwd_tile_kernel(
+    const CeArgs a, const float* __restrict__ logits, const int64_t* __restrict__ labels,
+    const float* __restrict__ pw, const float* __restrict__ cw, const float* __restrict__ lse,
+    float gscale, int sy, int sx, float* __restrict__ part, int cp) {
+  __shared__ float sh[4][4 * TCH];
+  const int tw = a.d.w + 1, th = a.d.h + 1;
+  const int tx = blockIdx.x % tw;
+  const int r = blockIdx.x / tw;
+  const int ty = r % th;
+  const int n = r / th;
+  const int y0 = max(0, ty * sy - (sy + 1) / 2), y1 = min(a.d.H, ty * sy - (sy + 1) / 2 + sy);
+  const int x0 = max(0, tx * sx - (sx + 1) / 2), x1 = min(a.d.W, tx * sx - (sx + 1) / 2 + sx);
+  const int nx = x1 - x0, npx = (y1 - y0) * nx;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* prow = part + (long)blockIdx.x * 4 * cp;
+  for (int c0 = 0; c0 < a.d.Cls; c0 += TCH) {
+    const int nc = min(TCH, a.d.Cls - c0);
+    float a00[TCH], a01[TCH], a10[TCH], a11[TCH];   // corner (row slot, column slot) sums
+#pragma unroll
+    for (int c = 0; c < TCH; ++c) { a00[c] = 0.f; a01[c] = 0.f; a10[c] = 0.f; a11[c] = 0.f; }
+    for (int q = threadIdx.x; q < npx; q += 256) {
+      const int Y = y0 + q / nx, X = x0 + q % nx;
+      const long pi = ((long)n * a.d.H + Y) * a.d.W + X;
+      const long lab = labels[pi];
+      if (lab == a.d.ignore_index || lab < 0 || lab >= a.d.Cls) continue;
+      float coef = gscale;
+      if (cw) coef *= cw[lab];
+      if (pw) coef *= pw[pi];
+      if (coef == 0.f) continue;
+      const Lerp ly = lerp_coord(Y, a.sh, a.d.h, 0);
+      const Lerp lx = lerp_coord(X, a.sw, a.d.w, 0);
+      // slot 1 = low-resolution index ty (tx), slot 0 = the one before it
+      const float wy1 = (ly.i0 == ty ? ly.l0 : 0.f) + (ly.i1 == ty ? ly.l1 : 0.f);
+      const float wy0 = (ly.i0 != ty ? ly.l0 : 0.f) + (ly.i1 != ty ? ly.l1 : 0.f);
+      const float wx1 = (lx.i0 == tx ? lx.l0 : 0.f) + (lx.i1 == tx ? lx.l1 : 0.f);
+      const float wx0 = (lx.i0 != tx ? lx.l0 : 0.f) + (lx.i1 != tx ? lx.l1 : 0.f);
+      const float w00 = wy0 * wx0 * coef, w01 = wy0 * wx1 * coef, w10 = wy1 * wx0 * coef,
+                  w11 = wy1 * wx1 * coef;
+      const float l = lse[pi];
+      const float* b = logits + (long)n * a.d.l_sn;
+      Taps t;
+      t.p00 = b + ly.i0 * a.d.l_sh + lx.i0 * a.d.l_sw;
+      t.p01 = b + ly.i0 * a.d.l_sh + lx.i1 * a.d.l_sw;
+      t.p10 = b + ly.i1 * a.d.l_sh + lx.i0 * a.d.l_sw;
+      t.p11 = b + ly.i1 * a.d.l_sh + lx.i1 * a.d.l_sw;
+      t.w00 = lx.l0; t.w01 = lx.l1; t.w10 = ly.l0; t.w11 = ly.l1;
+#pragma unroll
+      for (int c = 0; c < TCH; ++c) {
+        if (c < nc) {
+          const float z = tap_value(t, (long)(c0 + c) * a.d.l_sc);
+          float p = expf(z - l);
+          if (c0 + c == lab) p -= 1.f;
+          a00[c] += w00 * p; a01[c] += w01 * p; a10[c] += w10 * p; a11[c] += w11 * p;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < TCH; ++c) {
+      const float v0 = wave_sum(a00[c]), v1 = wave_sum(a01[c]), v2 = wave_sum(a10[c]),
+                  v3 = wave_sum(a11[c]);
+      if (lane == 0) {
+        sh[wave][c] = v0; sh[wave][TCH + c] = v1; sh[wave][2 * TCH + c] = v2;
+        sh[wave][3 * TCH + c] = v3;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * TCH) {
+      const int slot = threadIdx.x / TCH, c = threadIdx.x - slot * TCH;
+      if (c < nc)
+        prow[slot * cp + c0 + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] +
+                                   sh[3][threadIdx.x];
+    }
+    __syncthreads();
+  }
+}
+
+// dlogits[n, y, x, c] = corner sums of the four tiles around low-resolution pixel (y, x)
+__global__ __launch_bounds__(256) void ce_bwd_gather_kernel(const float* __restrict__ part, int N,
+                                                            int h, int w, int Cls, int cp,
+                                                            float* __restrict__ dlogits, int ld_d) {
+  const long total = (long)N * h * w * ld_d;
+  const int tw = w + 1, th = h + 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ld_d);
+    const long px = i / ld_d;
+    float v = 0.f;
+    if (c < Cls) {
+      const int x = (int)(px % w);
+      const long r = px / w;
+      const int y = (int)(r % h), n = (int)(r / h);
+      const long t11 = ((long)n * th + y) * tw + x;   // tile (y, x): this pixel is its slot (1, 1)
+      v = part[((t11 + tw + 1) * 4 + 0) * cp + c];    // tile (y+1, x+1), slot (0, 0)
+      v += part[((t11 + tw) * 4 + 1) * cp + c];       // tile (y+1, x  ), slot (0, 1)
+      v += part[((t11 + 1) * 4 + 2) * cp + c];        // tile (y,   x+1), slot (1, 0)
+      v += part[(t11 * 4 + 3) * cp + c];              // tile (y,   x  ), slot (1, 1)
+    }
+    dlogits[i] = v;
+  }
+}
+
 // argmax (and optional softmax probabilities) of the resized logits
 __global__ __launch_bounds__(256) void resize_argmax_kernel(const CeArgs a,
                                                             const float* __restrict__ logits,
@@ -276,6 +387,47 @@ extern "C" int gs_ce_backward(const gs_ce_desc* d, const float* logits, const in
   if (ld_d < d->Cls) return GS_E_BADARG;
   hipLaunchKernelGGL(ce_bwd_kernel, dim3(d->N * d->h * d->w), dim3(256), 0, as_stream(stream), a,
                      logits, labels, pixel_weight, class_weight, lse, grad_scale, dlogits, ld_d);
+  return launch_status();
+}
+
+static bool ce_tile_scales(const gs_ce_desc* d, int& sy, int& sx) {
+  if (d->align_corners || d->H % d->h || d->W % d->w) return false;
+  sy = d->H / d->h; sx = d->W / d->w;
+  auto pow2 = [](int v) { return v >= 2 && (v & (v - 1)) == 0; };
+  return pow2(sy) && pow2(sx);
+}
+
+extern "C" size_t gs_ce_backward_workspace_bytes(const gs_ce_desc* d, int32_t ld_d) {
+  int sy, sx;
+  if (!d || !ce_tile_scales(d, sy, sx)) return 0;
+  return (size_t)d->N * (d->h + 1) * (d->w + 1) * 4 * ld_d * sizeof(float);
+}
+
+// As gs_ce_backward; with a workspace of gs_ce_backward_workspace_bytes() and a power-of-two
+// integer up-scaling the tile form is used (each softmax term evaluated once instead of four times).
+extern "C" int gs_ce_backward_ws(const gs_ce_desc* d, const float* logits, const int64_t* labels,
+                                 const float* pixel_weight, const float* class_weight,
+                                 const float* lse, float grad_scale, float* dlogits, int32_t ld_d,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  CeArgs a;
+  int rc = check_ce(d, a);
+  if (rc) return rc;
+  if (!logits || !labels || !lse || !dlogits) return GS_E_NULL;
+  if (ld_d < d->Cls) return GS_E_BADARG;
+  int sy = 0, sx = 0;
+  const size_t need = gs_ce_backward_workspace_bytes(d, ld_d);
+  static const bool no_tile = getenv("GS_CE_NO_TILE") != nullptr;
+  if (no_tile || !ce_tile_scales(d, sy, sx) || !workspace || workspace_bytes < need)
+    return gs_ce_backward(d, logits, labels, pixel_weight, class_weight, lse, grad_scale, dlogits,
+                          ld_d, stream);
+  hipStream_t st = as_stream(stream);
+  float* part = static_cast<float*>(workspace);
+  const int tiles = d->N * (d->h + 1) * (d->w + 1);
+  hipLaunchKernelGGL(ce_bwd_tile_kernel, dim3(tiles), dim3(256), 0, st, a, logits, labels,
+                     pixel_weight, class_weight, lse, grad_scale, sy, sx, part, ld_d);
+  const long total = (long)d->N * d->h * d->w * ld_d;
+  hipLaunchKernelGGL(ce_bwd_gather_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, part,
+                     d->N, d->h, d->w, d->Cls, ld_d, dlogits, ld_d);
   return launch_status();
 }
 

@@ -78,10 +78,13 @@ class _FusedResizeCE(torch.autograd.Function):
         ld = round_up(c, 4)
         buf = torch.empty((n, h, w, ld), dtype=torch.float32, device=logits.device)
         pw, cw = ctx.pixel_weight, ctx.class_weight
-        _lib.check(L.gs_ce_backward(ctypes.byref(d), logits.data_ptr(), label.data_ptr(),
-                                    pw.data_ptr() if pw is not None else None,
-                                    cw.data_ptr() if cw is not None else None, lse.data_ptr(), 1.0,
-                                    buf.data_ptr(), ld, current_stream_ptr()), "gs_ce_backward")
+        nb = L.gs_ce_backward_workspace_bytes(ctypes.byref(d), ld)
+        ws = WORKSPACE.get(nb, logits.device)
+        _lib.check(L.gs_ce_backward_ws(ctypes.byref(d), logits.data_ptr(), label.data_ptr(),
+                                       pw.data_ptr() if pw is not None else None,
+                                       cw.data_ptr() if cw is not None else None, lse.data_ptr(),
+                                       1.0, buf.data_ptr(), ld, ws.data_ptr(), ws.numel(),
+                                       current_stream_ptr()), "gs_ce_backward_ws")
         # scale by the upstream scalar on device (no host sync); the tensor is low resolution
         buf.mul_(grad_loss)
         dlogits = buf[..., :c].permute(0, 3, 1, 2)

@@ -295,6 +295,17 @@ int gs_ce_forward(const gs_ce_desc* d, const float* logits, const int64_t* label
 int gs_ce_backward(const gs_ce_desc* d, const float* logits, const int64_t* labels,
                    const float* pixel_weight, const float* class_weight, const float* lse,
                    float grad_scale, float* dlogits, int32_t ld_d, void* stream);
+/* Same result through the tile form when the up-scaling is a power-of-two integer factor with
+ * align_corners = 0 (every mmseg head of this path: x8 / x16 / x32): one workgroup per tile of
+ * full-resolution pixels between four low-resolution logit pixels evaluates each softmax term once
+ * (the gather form of gs_ce_backward evaluates it once per neighbour, i.e. four times), then a
+ * fixed-order gather adds the four corner sums per low-resolution pixel.  Falls back to
+ * gs_ce_backward otherwise.  workspace >= gs_ce_backward_workspace_bytes(d, ld_d). */
+size_t gs_ce_backward_workspace_bytes(const gs_ce_desc* d, int32_t ld_d);
+int gs_ce_backward_ws(const gs_ce_desc* d, const float* logits, const int64_t* labels,
+                      const float* pixel_weight, const float* class_weight, const float* lse,
+                      float grad_scale, float* dlogits, int32_t ld_d, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* OHEMPixelSampler support: prob[n,Y,X] = softmax(resized logit)[label]
  * for valid pixels, 2.0 for ignored ones (so they sort last). */
 int gs_ce_label_prob(const gs_ce_desc* d, const float* logits, const int64_t* labels, float* prob,
