@@ -23,7 +23,7 @@ def short(name):
 
 
 def group(name):
-    if "igemm_rows_fast_kernel" in name:     # <BM, BN, BTRANS, KS, ABL>
+    if "igemm_rows_fast_kernel" in name:     # <BM, BN, BTRANS, KS, ABL, ROLE, PIPE, PAIR>
         t = name.split("<")[1].split(">")[0].split(", ")
         if len(t) > 5 and t[5] == "1":
             return K3
@@ -33,7 +33,10 @@ def group(name):
         t = name.split("<")[1].split(">")[0].split(", ")
         kind = "conv dgrad" if t[2] == "true" else "conv forward"
         return "%s %s" % (kind, {"1": "1x1", "3": "3x3"}.get(t[5], "stem/other"))
-    if "igemm_wgrad" in name:                # <BM, BN, KS> or <BM, BN, SCALAR, KS>
+    if "igemm_wgrad_fast" in name:           # <BM, BN, KS, PAIR>
+        ks = name.split("<")[1].split(">")[0].split(", ")[2]
+        return "conv wgrad %s" % {"1": "1x1", "3": "3x3"}.get(ks, "stem/other")
+    if "igemm_wgrad" in name:                # general kernel <BM, BN, SCALAR, KS>
         ks = name.split("<")[1].split(">")[0].split(", ")[-1]
         return "conv wgrad %s" % {"1": "1x1", "3": "3x3"}.get(ks, "stem/other")
     if "splitk_reduce_kernel<false, 1>" in name:
