@@ -1055,7 +1055,10 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_kernel(const IgemmArgs p) {
 // index math hoisted / incremental, bounds-checked buffer loads (no branches), and THREE K steps
 // of global loads in flight (three register sets, statically rotated).
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int KS, bool PAIR = false>
+// WALIGN: Wp % BK == 0, so the BK pixels of a K step lie in one image row: (n, h, w0) of the step are
+// scalars and the per-thread gather state (three counters with carries, ~20 VALU per K step inside
+// the MFMA stream) reduces to two adds.
+template <int BM, int BN, int KS, bool PAIR = false, bool WALIGN = false>
 __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
   __shared__ __attribute__((aligned(16))) float lds[PAIR ? T::LDSF2 : T::LDSF];
@@ -1126,8 +1129,40 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
   const int adv_w = BK % p.Wp, adv_q = BK / p.Wp;
   const int adv_h = adv_q % p.Hp, adv_n = adv_q / p.Hp;
   int k_left = nk;
+  // WALIGN scalar pixel state of the next K step
+  int s_n = 0, s_h = 0, s_w0 = 0;
+  if constexpr (WALIGN) {
+    const int m0 = kt0 * BK;
+    s_n = m0 / hw;
+    const int rem = m0 - s_n * hw;
+    s_h = rem / p.Wp;
+    s_w0 = rem - s_h * p.Wp;
+  }
+  const int cw_off = krA * p.mul_w + offw;   // + s * KSTR * mul_w per slot
   auto load_a = [&](f32x4 (&ra)[AS]) __attribute__((always_inline)) {
     const bool kvalid = k_left > 0;
+    if constexpr (WALIGN) {
+      const bool rowv = kvalid && s_n < Nb;
+      const int hb = s_h * p.mul_h, wb = s_w0 * p.mul_w;
+      const int nbase = s_n * (int)p.s_n;
+      const int hi = hb + offh;
+#pragma unroll
+      for (int s = 0; s < AS; ++s) {
+        const int wi = wb + cw_off + s * KSTR * p.mul_w;
+        const bool ok = rowv && iv && (unsigned)hi < (unsigned)p.Hs && (unsigned)wi < (unsigned)p.Ws;
+        const unsigned off =
+            ok ? 4u * (unsigned)(nbase + hi * (int)p.s_h + wi * (int)p.s_w + c) : kOOB;
+        ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
+      }
+      const int w2 = s_w0 + BK;
+      const int cw = w2 >= p.Wp ? 1 : 0;
+      s_w0 = w2 * (1 - cw);
+      const int h2 = s_h + cw;
+      const int ch = h2 >= p.Hp ? 1 : 0;
+      s_h = h2 * (1 - ch);
+      s_n += ch;
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < AS; ++s) {
       const int hi = ph[s] * p.mul_h + offh, wi = pw[s] * p.mul_w + offw;
@@ -1440,12 +1475,18 @@ static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t
   const dim3 grid(pl.tiles_m * pl.tiles_n * pl.splits), block(NT);
   const bool pair = pl.nk_per_split >= pair_min_ksteps() &&
                     (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
+  static const int no_walign = env_int("GS_NO_WALIGN", 0);
+  const bool walign = !no_walign && a.Wp % BK == 0;
 #define GS_WGF(BM_, BN_)                                                                  \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                     \
-    if (pair)                                                                             \
-      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS, true>), grid, block, dyn_lds(), st, a); \
+    if (pair && walign)                                                                   \
+      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS, true, true>), grid, block, dyn_lds(), st, a); \
+    else if (pair)                                                                        \
+      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS, true, false>), grid, block, dyn_lds(), st, a); \
+    else if (walign)                                                                      \
+      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS, false, true>), grid, block, dyn_lds(), st, a); \
     else                                                                                  \
-      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS>), grid, block, dyn_lds(), st, a);   \
+      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<BM_, BN_, KS, false, false>), grid, block, dyn_lds(), st, a); \
     return;                                                                               \
   }
   GS_WGF(128, 128) GS_WGF(128, 96) GS_WGF(128, 80) GS_WGF(128, 64) GS_WGF(128, 48) GS_WGF(128, 32)
