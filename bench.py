@@ -180,6 +180,9 @@ def main():
 
     if runner.host_prof is not None:
         runner.host_prof.clear()
+    # the timed steps always see draws 1..K of the seeded train sampler, whatever the warm-up
+    # length was (the subnet mix decides the step time: the number must not depend on --warmup)
+    sampler.seed(args.seed)
     timer = None
     if not args.no_k3_timer:
         # HIP events on the launch stream around every bottleneck-conv2 forward (conv + its split-K
