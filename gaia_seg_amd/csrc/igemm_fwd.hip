@@ -117,3 +117,14 @@ extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const fl
                              nullptr);
 }
 
+
+// Tuning / test hook: the plan the library would use for a GEMM of M x N x K (rows kernels:
+// max_splits = 64; wgrad: 512).  Pure host arithmetic.
+extern "C" int gs_debug_query_plan(int32_t M, int32_t N, int32_t K, int32_t max_splits, int32_t* bm,
+                                   int32_t* bn, int32_t* splits, int32_t* ksteps_per_split) {
+  if (!bm || !bn || !splits || !ksteps_per_split) return GS_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || max_splits <= 0) return GS_E_BADARG;
+  const Plan pl = make_plan(M, N, K, true, max_splits);
+  *bm = pl.bm; *bn = pl.bn; *splits = pl.splits; *ksteps_per_split = pl.nk_per_split;
+  return GS_OK;
+}

@@ -103,6 +103,8 @@ PROTOTYPES = {
     "gs_confusion_matrix": (_i32, [_P, _P, _i64, _i32, _i32, _P, _P]),
     "gs_sgd_step": (_i32, [_P, _P, _P, _i64, _f32, _f32, _f32, _f32, _P]),
     "gs_debug_force_plan": (_i32, [_i32, _i32, _i32]),
+    "gs_debug_query_plan": (_i32, [_i32, _i32, _i32, _i32, POINTER(_i32), POINTER(_i32), POINTER(_i32),
+                                   POINTER(_i32)]),
     "gs_stream_fork": (_i32, [_P, _P]),
     "gs_conv_bn_workspace_bytes": (_sz, [_CD]),
     "gs_conv_bn_forward": (_i32, [_CD, _P, _P, _BN, _P, _i32, _P, _P, _P, _i32, _P, _sz, _P]),

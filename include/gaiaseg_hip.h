@@ -358,6 +358,10 @@ int gs_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
 /* order of split-K changes).                                                                  */
 /* ------------------------------------------------------------------------------------------ */
 int gs_debug_force_plan(int32_t bm, int32_t bn, int32_t splits);
+/* The tile / split-K plan the library would choose for an M x N x K implicit GEMM (max_splits: 64 for
+ * forward / dgrad, 512 for wgrad).  Host arithmetic only (no GPU needed). */
+int gs_debug_query_plan(int32_t M, int32_t N, int32_t K, int32_t max_splits, int32_t* bm,
+                        int32_t* bn, int32_t* splits, int32_t* ksteps_per_split);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Stream fork / join: work enqueued on `to` after this call waits for everything enqueued on  */

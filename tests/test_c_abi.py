@@ -73,3 +73,36 @@ def test_product_path_fails_loudly_without_gpu_tensor():
         DynamicConv2d(8, 8, 3, padding=1)(torch.randn(1, 8, 4, 4))
     with pytest.raises(lib.HipLibraryError):
         DynamicBatchNorm2d(8)(torch.randn(2, 8, 4, 4))
+
+
+def _plan(L, M, N, K, max_splits=64):
+    bm, bn, sp, ks = (ctypes.c_int32() for _ in range(4))
+    assert L.gs_debug_query_plan(M, N, K, max_splits, ctypes.byref(bm), ctypes.byref(bn),
+                                 ctypes.byref(sp), ctypes.byref(ks)) == 0
+    return bm.value, bn.value, sp.value, ks.value
+
+
+def test_conv_planner_invariants_need_no_gpu():
+    """The tile / split-K cost model (csrc/igemm_core.h make_plan) is host arithmetic: check its
+    invariants and a few decisions the r01 sweeps pinned down."""
+    L = lib.load()
+    shapes = [(65536, 64, 576), (16384, 128, 1152), (4096, 256, 2304), (1024, 512, 4608),
+              (1024, 512, 18432), (4096, 192, 1728), (65536, 256, 64), (1024, 2048, 512), (99, 48, 1152)]
+    for M, N, K in shapes:
+        for ms in (64, 512):
+            bm, bn, sp, ks = _plan(L, M, N, K, ms)
+            nk = -(-K // 16)
+            assert bm == 64 and bn in (80, 64, 48, 32)
+            assert 1 <= sp <= ms and sp * ks >= nk and (sp - 1) * ks < nk     # K range covered exactly
+            assert sp == 1 or ks >= 4                                          # no degenerate splits
+            assert sp * M * N * 4 <= 96 << 20 or sp == 1                        # slab bound
+            assert _plan(L, M, N, K, ms) == (bm, bn, sp, ks)                    # deterministic (cached)
+    # a grid that already fills the chip several times over is never split
+    assert _plan(L, 65536, 64, 576)[2] == 1
+    assert _plan(L, 65536, 256, 64)[2] == 1
+    # few tiles and a long K range: split until the workgroups make whole rounds of the 256 CUs
+    bm, bn, sp, ks = _plan(L, 1024, 512, 18432)
+    tiles = (1024 // 64) * -(-512 // bn)
+    assert sp > 1 and (tiles * sp) % 256 == 0
+    # the least-padded width wins when the tile count is comparable
+    assert _plan(L, 16384, 96, 864)[1] == 48
