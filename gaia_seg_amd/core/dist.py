@@ -42,8 +42,25 @@ def broadcast_object(obj, src=0):
     if not is_dist():
         return obj
     box = [obj]
-    dist.broadcast_object_list(box, src=src)
+    dist.broadcast_object_list(box, src=src, group=_host_group())
     return box[0]
+
+
+_HOST_GROUP = None
+
+
+def _host_group():
+    """A gloo group for small host objects (the per-step subnet meta).  Broadcasting a pickled
+    object over the RCCL group moves its size to the GPU and reads it back, i.e. one full
+    host<->GPU synchronisation per training step: the host could never run ahead of the GPU.
+    Every rank reaches the first call at the same point (collective creation)."""
+    global _HOST_GROUP
+    if _HOST_GROUP is None:
+        if dist.get_backend() == "gloo":
+            _HOST_GROUP = dist.group.WORLD
+        else:
+            _HOST_GROUP = dist.new_group(backend="gloo")
+    return _HOST_GROUP
 
 
 class GradReducer:

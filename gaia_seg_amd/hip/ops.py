@@ -236,7 +236,7 @@ class BNParams:
         self.num_batches_tracked = num_batches_tracked
 
 
-def _sync_stats(sums, count, C, pg):
+def _sync_stats(sums, count, C, pg, equal_counts=False):
     """SyncBN: merge per-rank (shifted sums, count) into global statistics (Chan et al.).
 
     Mirrors torch.nn.SyncBatchNorm's all_gather of [mean, var, count]; the
@@ -246,7 +246,10 @@ def _sync_stats(sums, count, C, pg):
     d1 = sums[:C].double() / count
     mean = sums[2 * C:3 * C].double() + d1
     var = (sums[C:2 * C].double() / count - d1 * d1).clamp_(min=0)
-    local = torch.cat([mean, var, torch.tensor([count], dtype=torch.float64, device=sums.device)])
+    # (torch.full, not torch.tensor([...], device=...): a host-to-device copy from pageable memory
+    # synchronises the stream and would stall the host once per SyncBN layer and step)
+    local = torch.cat([mean, var, torch.full((1,), float(count), dtype=torch.float64,
+                                             device=sums.device)])
     gathered = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(gathered, local, group=pg)
     g = torch.stack(gathered)                     # [world, 2C+1]
@@ -258,7 +261,14 @@ def _sync_stats(sums, count, C, pg):
     merged[:C] = 0
     merged[C:2 * C] = (gvar * total).float()
     merged[2 * C:3 * C] = gmean.float()
-    return merged, float(total.item())
+    if not equal_counts:
+        return merged, float(total.item())   # exact for any per-rank counts; synchronises the host
+    # equal_counts: every rank holds the same batch and crop size (the training path: fixed
+    # samples_per_gpu and crop), so the total is count * world and is NOT read back from the device
+    # -- a .item() here drains the GPU queue once per SyncBN layer and step, which serialises host
+    # and GPU in multi-GPU runs.  (The weighting of the per-rank statistics above uses the
+    # gathered counts either way.)
+    return merged, float(count) * world
 
 
 def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
@@ -293,7 +303,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
         else:
             _lib.check(L.gs_bn_stats(x.ptr, rows, C, x.ld, sums_ptr, ws.data_ptr(),
                                      ws.numel(), st), "gs_bn_stats")
-            merged, count = _sync_stats(buf[:3 * C], count, C, bn.process_group)
+            merged, count = _sync_stats(buf[:3 * C], count, C, bn.process_group, equal_counts=True)
             _lib.check(L.gs_bn_finalize(merged.data_ptr(), count, C, gamma, beta, bn.eps, mom, rm,
                                         rv, coeffs_ptr, st), "gs_bn_finalize")
         if bn.training and bn.num_batches_tracked is not None:
