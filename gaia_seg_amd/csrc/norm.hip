@@ -501,6 +501,46 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(
   }
 }
 
+
+// ---------------- SyncBN exchange helpers (one launch each instead of ~25 tiny tensor ops) -------
+// local[0..C) = mean, local[C..2C) = biased variance, local[2C] = count  (double), from the shifted
+// sums {S1, S2, shift} of gs_bn_stats: the payload a rank contributes to the all_gather.
+__global__ __launch_bounds__(256) void bn_sync_local_kernel(const float* __restrict__ sums,
+                                                            double count, int C,
+                                                            double* __restrict__ local) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) local[2 * C] = count;
+  if (c >= C) return;
+  const double d1 = (double)sums[c] / count;
+  double var = (double)sums[C + c] / count - d1 * d1;
+  if (var < 0.0) var = 0.0;
+  local[c] = (double)sums[2 * C + c] + d1;
+  local[C + c] = var;
+}
+// gathered[world][2C+1] -> merged sums {0, gvar * total, gmean} (float) for gs_bn_finalize:
+// gmean = sum n_r m_r / N, gvar = sum n_r (v_r + (m_r - gmean)^2) / N (Chan et al.), rank order.
+__global__ __launch_bounds__(256) void bn_sync_merge_kernel(const double* __restrict__ g, int world,
+                                                            int C, float* __restrict__ merged) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int ld = 2 * C + 1;
+  double total = 0.0, msum = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double n = g[(long)r * ld + 2 * C];
+    total += n;
+    msum += n * g[(long)r * ld + c];
+  }
+  const double gmean = msum / total;
+  double vsum = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double n = g[(long)r * ld + 2 * C], dm = g[(long)r * ld + c] - gmean;
+    vsum += n * (g[(long)r * ld + C + c] + dm * dm);
+  }
+  merged[c] = 0.f;
+  merged[C + c] = (float)vsum;          // = gvar * total
+  merged[2 * C + c] = (float)gmean;
+}
+
 // ---- host helpers ----
 struct RedGeom {
   int gx, gy;
@@ -737,5 +777,23 @@ extern "C" int gs_colsum(const float* src, int64_t rows, int32_t C, int32_t ld, 
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(g.gx, g.gy), dim3(256), 0, st, src, (long)rows, C,
                      ld, g.rows_per_block, part);
   launch_sum_partials(part, g.gx, C, out, nullptr, 0, st);
+  return launch_status();
+}
+
+extern "C" int gs_bn_sync_local(const float* sums, double count, int32_t C, double* local,
+                                void* stream) {
+  if (!sums || !local) return GS_E_NULL;
+  if (C <= 0 || count <= 0.0) return GS_E_BADARG;
+  hipLaunchKernelGGL(bn_sync_local_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream),
+                     sums, count, C, local);
+  return launch_status();
+}
+
+extern "C" int gs_bn_sync_merge(const double* gathered, int32_t world, int32_t C, float* merged,
+                                void* stream) {
+  if (!gathered || !merged) return GS_E_NULL;
+  if (C <= 0 || world <= 0) return GS_E_BADARG;
+  hipLaunchKernelGGL(bn_sync_merge_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream),
+                     gathered, world, C, merged);
   return launch_status();
 }

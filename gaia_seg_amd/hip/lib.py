@@ -66,6 +66,8 @@ PROTOTYPES = {
     "gs_bn_stats_workspace_bytes": (_sz, [_i64, _i32]),
     "gs_bn_stats": (_i32, [_P, _i64, _i32, _i32, _P, _P, _sz, _P]),
     "gs_bn_finalize": (_i32, [_P, _f64, _i32, _P, _P, _f32, _f32, _P, _P, _P, _P]),
+    "gs_bn_sync_local": (_i32, [_P, _f64, _i32, _P, _P]),
+    "gs_bn_sync_merge": (_i32, [_P, _i32, _i32, _P, _P]),
     "gs_bn_stats_finalize": (_i32, [_P, _i64, _i32, _i32, _P, _P, _f32, _f32, _P, _P, _P, _P, _sz,
                                     _P]),
     "gs_bn_eval_coeffs": (_i32, [_P, _P, _i32, _P, _P, _f32, _P, _P]),

@@ -243,6 +243,22 @@ def _sync_stats(sums, count, C, pg, equal_counts=False):
     payload is 2C+1 floats per rank."""
     import torch.distributed as dist
     world = dist.get_world_size(pg)
+    if sums.is_cuda and equal_counts:
+        # device path of the training step: two launches around one all_gather
+        L = _L()
+        st = current_stream_ptr()
+        local = torch.empty(2 * C + 1, dtype=torch.float64, device=sums.device)
+        _lib.check(L.gs_bn_sync_local(sums.data_ptr(), float(count), C, local.data_ptr(), st),
+                   "gs_bn_sync_local")
+        gathered = torch.empty((world, 2 * C + 1), dtype=torch.float64, device=sums.device)
+        if dist.get_backend(pg) == "nccl":
+            dist.all_gather_into_tensor(gathered, local, group=pg)
+        else:   # gloo (tests, rehearsals): list form, rows of `gathered` as outputs
+            dist.all_gather([gathered[r] for r in range(world)], local, group=pg)
+        merged = torch.empty(3 * C, dtype=torch.float32, device=sums.device)
+        _lib.check(L.gs_bn_sync_merge(gathered.data_ptr(), world, C, merged.data_ptr(), st),
+                   "gs_bn_sync_merge")
+        return merged, float(count) * world
     d1 = sums[:C].double() / count
     mean = sums[2 * C:3 * C].double() + d1
     var = (sums[C:2 * C].double() / count - d1 * d1).clamp_(min=0)

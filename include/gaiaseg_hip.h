@@ -121,6 +121,13 @@ int gs_bn_stats(const float* x, int64_t rows, int32_t C, int32_t ldx, float* sum
 int gs_bn_finalize(const float* sums, double count, int32_t C, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, float* coeffs, void* stream);
+/* SyncBN exchange (torch.nn.SyncBatchNorm's all_gather of [mean, var, count]; heads
+ * with norm_cfg SyncBN): gs_bn_sync_local turns the shifted sums of gs_bn_stats into this rank's
+ * payload local[2C+1] = {mean[C], biased var[C], count} (double); after the host's all_gather into
+ * gathered[world][2C+1], gs_bn_sync_merge produces the merged sums {0, gvar*total, gmean}[3C] that
+ * gs_bn_finalize takes (count = total).  One launch each. */
+int gs_bn_sync_local(const float* sums, double count, int32_t C, double* local, void* stream);
+int gs_bn_sync_merge(const double* gathered, int32_t world, int32_t C, float* merged, void* stream);
 /* gs_bn_stats + gs_bn_finalize in two launches instead of three, for rank-local statistics
  * (count = rows).  Bit-identical to the separate calls. */
 int gs_bn_stats_finalize(const float* x, int64_t rows, int32_t C, int32_t ldx, const float* gamma,

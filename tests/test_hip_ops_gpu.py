@@ -451,3 +451,39 @@ def test_conv_bn_fused_equals_module_by_module(hip_lib, monkeypatch):
             assert torch.equal(outs[0], outs[1])
         else:
             assert rel_err(outs[0], outs[1]) < 1e-5
+
+
+def test_syncbn_exchange_kernels_match_the_formula(hip_lib):
+    """gs_bn_sync_local / gs_bn_sync_merge (the device path of the SyncBN statistics exchange)
+    against the tensor formula (Chan et al.) on a fake three-rank gather with unequal counts."""
+    import ctypes
+    from gaia_seg_amd.hip import lib
+    L = lib.load()
+    torch.manual_seed(5)
+    C, counts = 24, [40.0, 25.0, 70.0]
+    st = torch.cuda.current_stream().cuda_stream
+    gathered = torch.empty((3, 2 * C + 1), dtype=torch.float64, device=DEV)
+    ref_mean, ref_var = [], []
+    for r, n in enumerate(counts):
+        x = torch.randn(int(n), C, dtype=torch.float64) * (1 + r) + r
+        shift = x[0].clone()
+        d = x - shift
+        sums = torch.cat([d.sum(0), (d * d).sum(0), shift]).float().to(DEV)
+        lib.check(L.gs_bn_sync_local(sums.data_ptr(), n, C, gathered[r].data_ptr(), st), "local")
+        ref_mean.append(x.mean(0))
+        ref_var.append(x.var(0, unbiased=False))
+    g = gathered.cpu()
+    for r in range(3):
+        assert torch.allclose(g[r, :C], ref_mean[r], atol=1e-5)
+        assert torch.allclose(g[r, C:2 * C], ref_var[r], rtol=1e-4, atol=1e-5)
+        assert float(g[r, 2 * C]) == counts[r]
+    merged = torch.empty(3 * C, dtype=torch.float32, device=DEV)
+    lib.check(L.gs_bn_sync_merge(gathered.data_ptr(), 3, C, merged.data_ptr(), st), "merge")
+    total = sum(counts)
+    cnt = torch.tensor(counts, dtype=torch.float64)[:, None]
+    gmean = (g[:, :C] * cnt).sum(0) / total
+    gvar = ((g[:, C:2 * C] + (g[:, :C] - gmean) ** 2) * cnt).sum(0) / total
+    m = merged.cpu().double()
+    assert float(m[:C].abs().max()) == 0.0
+    assert torch.allclose(m[C:2 * C] / total, gvar, rtol=1e-5)
+    assert torch.allclose(m[2 * C:], gmean, atol=1e-5)
