@@ -9,13 +9,24 @@ A step = sample arch -> zero grads of the active ranges -> forward (HIP kernels)
 (HIP kernels) with the bucketed RCCL all-reduce of the active gradient ranges overlapped ->
 fused SGD(momentum, weight decay) with poly LR.  Nothing is skipped inside the timed region.
 
-Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the dynamic 3x3 bottleneck conv forward, timed live with HIP events on
-                 the launch stream inside the timed steps: achieved = sum(2*M*N*K FLOPs) / sum(time)
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process only launches
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (before anything touches
+the GPU) and exits with its code; the ranks are one process per GPU over RCCL.
+
+Rank 0 prints ONE JSON line.  `value` comes from K un-instrumented steps.  Besides the contract
+fields the line carries
+  check        : before any timing, the first timed step's subnet and batch are run once from the
+                 initial weights (dropout off: device RNG streams cannot match the CPU) and the
+                 losses compared with the committed oracle values (tests/golden/bench_check.json,
+                 made by tests/golden/make_bench_check.py); a mismatch > 1e-3 aborts the benchmark;
+  roofline     : the dynamic 3x3 bottleneck conv forward, timed with HIP events on the
+                 launch stream in a SEPARATE instrumented pass over the same K draws (so the
+                 instrumentation never sits inside `value`): achieved = sum(2*M*N*K FLOPs) / sum(time)
                  against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) — fp32 because the
                  reference path is fp32 and the parity bar is 1e-3 rel fp32;
+  roofline_step: algorithmic conv FLOPs of the K timed steps (fwd + dgrad + wgrad) / their wall time;
   cpu_baseline : the CPU oracle (oracle/model.py, PyTorch-CPU) timed on the host cores on a bounded
-                 sample of the same workload (N=1 only).
+                 sample of the same workload (N=1 only): median of >= 5 steps.
 """
 import argparse
 import json
@@ -33,8 +44,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default=os.path.join(ROOT, "configs/supernet/fcn_ar50to101v2.py"))
     ap.add_argument("--arch", default="sample",
                     help="'sample' = one subnet per step from the train sampler (config of record); "
@@ -42,7 +53,9 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", default="512x1024",
-                    help="HxW of the bounded CPU sample (bs 1, R50 anchor)")
+                    help="HxW of the bounded CPU sample (config batch size, R50 anchor)")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the oracle check of the first step (diagnostics only)")
     ap.add_argument("--no-k3-timer", action="store_true")
     ap.add_argument("--crop", default=None,
                     help="HxW override of the crop size (diagnostics only, e.g. 64x128 makes the GPU "
@@ -68,30 +81,42 @@ def k3_traffic():
     """HBM bytes per K3 launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
     rocprofv3 --pmc runs of this script; see profiles/r01_k3_traffic.json).  Counters cannot be
     read from inside the process, so this is the committed measurement, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_k3_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k3_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f)["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def cpu_baseline(cfg, size, seed):
-    """One fwd+bwd+SGD step of the oracle on the host cores: a bounded sample (bs 1, R50 anchor)."""
+def _plain(obj):
+    if isinstance(obj, dict):
+        return {k: _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_plain(v) for v in obj]
+    return obj
+
+
+R50 = {"arch.backbone.stem.width": 64, "arch.backbone.body.width": [64, 128, 256, 512],
+       "arch.backbone.body.depth": [3, 4, 6, 3]}
+
+
+def cpu_baseline(cfg, size, seed, bs):
+    """fwd+bwd+SGD steps of the oracle on the host cores: a bounded sample of the workload (the
+    config's batch size and crop, R50 anchor instead of the sampled mix), median of >= 5 steps."""
+    import statistics
     import torch
     from gaia_seg_amd.core.dynamic import fold_dict
     from gaia_seg_amd.core.synthetic import make_batch
     from oracle.model import OEncoderDecoder
     h, w = size
     torch.manual_seed(seed)
-    model_cfg = {k: v for k, v in cfg.model.to_dict().items() if k != "type"} \
-        if hasattr(cfg.model, "to_dict") else {k: v for k, v in dict(cfg.model).items() if k != "type"}
-    orc = OEncoderDecoder(**model_cfg).train()
-    r50 = {"arch.backbone.stem.width": 64, "arch.backbone.body.width": [64, 128, 256, 512],
-           "arch.backbone.body.depth": [3, 4, 6, 3]}
-    orc.manipulate_arch(fold_dict(r50)["arch"])
+    orc = OEncoderDecoder(**{k: v for k, v in _plain(cfg.model).items() if k != "type"}).train()
+    orc.manipulate_arch(fold_dict(R50)["arch"])
     opt = torch.optim.SGD(orc.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
-    batch = make_batch(1, h, w, seed=seed)
+    batch = make_batch(bs, h, w, seed=seed)
     cores = host_cores()
     torch.set_num_threads(cores)
 
@@ -100,24 +125,113 @@ def cpu_baseline(cfg, size, seed):
         loss, _ = orc.parse_losses(orc.forward_train(batch["img"], batch["gt_semantic_seg"]))
         loss.backward()
         opt.step()
-    step()  # warm-up (oneDNN primitive creation)
-    t0 = time.time()
-    n = 0
-    while True:
+    for _ in range(2):   # warm-up (oneDNN primitive creation, allocator)
         step()
-        n += 1
-        if time.time() - t0 > 8.0 or n >= 3:
-            break
-    dt = (time.time() - t0) / n
-    # images/sec scaled to the benchmark resolution by pixel count (conv work is linear in pixels)
-    scale = (h * w) / (512.0 * 1024.0)
-    return dict(value=round(scale / dt, 4), unit="images/sec", cores=cores, kind="port",
-                sample="oracle (PyTorch-CPU fp32) fwd+bwd+SGD, R50 anchor, bs 1 at %dx%d, %d timed "
-                       "step(s) of %.2f s, scaled by pixel count to 512x1024" % (h, w, n, dt))
+    times = []
+    t_all = time.time()
+    while len(times) < 5 or (time.time() - t_all < 12.0 and len(times) < 9):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    dt = statistics.median(times)
+    scale = (h * w) / (512.0 * 1024.0)   # conv work is linear in pixels (1.0 at the default size)
+    return dict(value=round(bs * scale / dt, 4), unit="images/sec", cores=cores, kind="port",
+                sample="oracle (PyTorch-CPU fp32, oneDNN) fwd+bwd+SGD, R50 anchor, bs %d at %dx%d: "
+                       "median %.2f s/step over %d timed steps after 2 warm-up steps"
+                       % (bs, h, w, dt, len(times)))
+
+
+def launch_ranks(n):
+    """--gpus N without a launcher: start N ranks as child processes (one per GPU, RCCL) and exit
+    with their code.  Nothing in this parent touches the GPU (a process that has initialised HIP
+    must never exec another program on this pool)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    cmd += sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def first_step_check(model, cfg_path, seed, size, bs, arch_meta, batch, dev):
+    """Run the first timed step's subnet and batch once from the initial weights with dropout off and
+    compare the losses with the committed oracle values.  Returns the `check` entry; raises on a
+    mismatch.  (The BN running statistics it moves and the gradients it leaves are part of the
+    warm-up state; nothing of it is timed.)"""
+    import torch
+    from gaia_seg_amd.core.dynamic import fold_dict
+    key = "%s|seed%d|%dx%d|bs%d|%s" % (os.path.basename(cfg_path), seed, size[0], size[1], bs,
+                                       arch_meta.get("name", "random"))
+    path = os.path.join(ROOT, "tests", "golden", "bench_check.json")
+    try:
+        with open(path) as f:
+            gold = json.load(f).get(key)
+    except (OSError, ValueError):
+        gold = None
+    if gold is None:
+        return dict(status="skipped", reason="no committed oracle value for %s" % key)
+    csum = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+    if abs(csum - gold["param_abs_sum"]) > 1e-9 * gold["param_abs_sum"]:
+        return dict(status="skipped", reason="initial weights differ from the fixture's (RNG stream): "
+                    "abs-sum %.9g vs %.9g" % (csum, gold["param_abs_sum"]))
+    heads = [h for h in (model.decode_head, getattr(model, "auxiliary_head", None)) if h is not None]
+    saved_h = [h.dropout for h in heads]
+    for h in heads:
+        h.dropout = None
+    try:
+        model.manipulate_arch(fold_dict(arch_meta)["arch"])
+        out = model.train_step(batch, None)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+    finally:
+        for h, d in zip(heads, saved_h):
+            h.dropout = d
+    got = {k: float(v) for k, v in out["log_vars"].items()}
+    worst = 0.0
+    for k, want in gold["log_vars"].items():
+        if k.endswith("acc_seg"):
+            continue
+        worst = max(worst, abs(got[k] - want) / max(abs(want), 1e-12))
+    res = dict(status="ok", what="first timed step's subnet (%s) and batch from the initial weights, "
+               "dropout off, vs committed CPU-oracle losses (tests/golden/bench_check.json)"
+               % arch_meta.get("name", "random"),
+               hip_loss=round(got["loss"], 6), oracle_loss=round(gold["log_vars"]["loss"], 6),
+               max_rel_err=float("%.3g" % worst), tol=1e-3)
+    if not worst < 1e-3:
+        raise SystemExit("bench.py: the HIP path's losses differ from the oracle's on the first step: "
+                         "%s vs %s" % (got, gold["log_vars"]))
+    return res
+
+
+def step_flops(model, sampler, seed, steps, size, bs, fixed_meta):
+    """Algorithmic conv FLOPs of the timed steps (forward + dgrad + wgrad = 3x forward, the stem
+    conv has no dgrad): replays the seeded draws on the host after the timing."""
+    from gaia_seg_amd.core.dynamic import fold_dict
+    from gaia_seg_amd.core.flops import _conv, model_flops
+    total = 0.0
+    if fixed_meta is None:
+        sampler.seed(seed)
+    for _ in range(steps):
+        meta = fixed_meta if fixed_meta is not None else sampler.sample()
+        model.manipulate_arch(fold_dict(meta)["arch"])
+        f = model_flops(model, size[0], size[1])
+        b = model.backbone
+        stem = 0.0 if b.deep_stem else _conv(b.conv1, 3, size[0], size[1])[0]
+        total += bs * (3.0 * f["total"] - stem)
+    return total
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)   # never returns
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,6 +244,9 @@ def main():
     backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
+    elif world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (RCCL needs one GPU per rank)"
+                         % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -148,67 +265,93 @@ def main():
     from gaia_seg_amd.core.param_arena import ParamArena
     from gaia_seg_amd.core.runner import (ArenaOptimizerHook, IterBasedRunner, ManipulateArchHook,
                                           PolyLrUpdaterHook)
-    from gaia_seg_amd.core.synthetic import SyntheticLoader
-    from gaia_seg_amd.hip import lib, ops
+    from gaia_seg_amd.core.synthetic import SyntheticLoader, make_batch
+    from gaia_seg_amd.hip import lib
     from gaia_seg_amd.models import build_segmentor
 
-    lib.load()
+    L = lib.load()
     cfg = Config.fromfile(args.config)
     torch.manual_seed(args.seed)
     random.seed(args.seed)
     model = build_segmentor(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg"))
     model = model.to(dev).train()
     arena = ParamArena(model)
+    gdist.sync_module_states(model, arena)   # the DDP wrap-time broadcast (gaiaseg/apis/train.py:88-96)
     reducer = gdist.GradReducer(arena.flat_grad, arena.segments)
     opt = cfg.optimizer
     runner = IterBasedRunner(model, arena, reducer, base_lr=opt["lr"], momentum=opt["momentum"],
                              weight_decay=opt["weight_decay"], max_iters=cfg.runner["max_iters"])
     sampler = build_model_sampler(cfg.train_sampler)
     sampler.seed(args.seed)
-    if args.arch == "sample":
-        runner.register_hook(ManipulateArchHook(sampler))
-    else:
+    fixed_meta = None
+    if args.arch != "sample":
         anchors = {a["name"]: a for a in sampler.model_samplers[0].anchors}
-        runner.set_arch(anchors[args.arch])
-    lrc = dict(cfg.lr_config)
-    lrc.pop("policy", None)
-    runner.register_hook(PolyLrUpdaterHook(**lrc))
-    runner.register_hook(ArenaOptimizerHook())
-    runner.call_hook("before_run")
+        fixed_meta = anchors[args.arch]
 
     bs = cfg.data["samples_per_gpu"]
     size = tuple(cfg.crop_size)
     if args.crop:
         size = tuple(int(v) for v in args.crop.split("x"))
+
+    # ---- parity gate: the first timed step's subnet and batch against the committed oracle losses
+    check = dict(status="skipped", reason="--no-check")
+    if not args.no_check:
+        first_meta = fixed_meta if fixed_meta is not None else sampler.sample()
+        sampler.seed(args.seed)
+        b0 = make_batch(bs, size[0], size[1], 19, args.seed * 1000003, dev)   # rank 0's first batch
+        check = first_step_check(model, args.config, args.seed, size, bs, first_meta, b0, dev)
+        arena.zero_grad()
+        del b0
+
+    if fixed_meta is None:
+        runner.register_hook(ManipulateArchHook(sampler))
+    else:
+        runner.set_arch(fixed_meta)
+    lrc = dict(cfg.lr_config)
+    lrc.pop("policy", None)
+    runner.register_hook(PolyLrUpdaterHook(**lrc))
+    runner.register_hook(ArenaOptimizerHook())
+    runner.call_hook("before_run")
     loader = SyntheticLoader(bs, size, num_classes=19, seed=args.seed, rank=rank, device=dev)
 
     for _ in range(args.warmup):
         runner.train_iter(next(loader))
     torch.cuda.synchronize()
 
+    def timed_pass(instrumented):
+        """K steps over draws 1..K of the seeded train sampler (whatever the warm-up length was:
+        the subnet mix decides the step time), bracketed by barrier + synchronize."""
+        sampler.seed(args.seed)
+        if instrumented:
+            lib.check(L.gs_k3_timer_enable(1), "gs_k3_timer_enable")
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            runner.train_iter(next(loader))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if instrumented:
+            lib.check(L.gs_k3_timer_enable(0), "gs_k3_timer_enable")
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     if runner.host_prof is not None:
         runner.host_prof.clear()
-    # the timed steps always see draws 1..K of the seeded train sampler, whatever the warm-up
-    # length was (the subnet mix decides the step time: the number must not depend on --warmup)
-    sampler.seed(args.seed)
-    timer = None
-    if not args.no_k3_timer:
-        # HIP events on the launch stream around every bottleneck-conv2 forward (conv + its split-K
-        # reduce), recorded inside the library (gs_k3_timer_*, include/gaiaseg_hip.h)
-        timer = lib.load()
-        lib.check(timer.gs_k3_timer_enable(1), "gs_k3_timer_enable")
     arch_log_start = runner.iter
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    bytes0 = reducer.bytes_reduced
     prof = None
     if os.environ.get("GS_CPROFILE"):   # diagnostics: host profile of the timed loop (main thread)
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.train_iter(next(loader))
+    elapsed = timed_pass(False)                      # <- `value`: nothing but the training steps
     if prof is not None:
         prof.disable()
         import pstats
@@ -217,23 +360,26 @@ def main():
         if _rt.BACKWARD_PROFILE is not None:
             print("---- backward thread ----", file=sys.stderr)
             pstats.Stats(_rt.BACKWARD_PROFILE, stream=sys.stderr).sort_stats("tottime").print_stats(30)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if timer is not None:
-        lib.check(timer.gs_k3_timer_enable(0), "gs_k3_timer_enable")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    bytes_per_step = (reducer.bytes_reduced - bytes0) / max(args.steps, 1)
+    arch_log_end = runner.iter
+    loss = float(runner.outputs["loss"].detach())
     if runner.host_prof:
         hp = runner.host_prof
         n = max(hp.pop("iters", 1), 1)
         print("host ms/iter: " + ", ".join("%s %.2f" % (k, 1e3 * v / n) for k, v in hp.items()),
               file=sys.stderr)
-    loss = float(runner.outputs["loss"].detach())
+    k3 = None
+    if not args.no_k3_timer:
+        # separate pass over the same draws with HIP events on the launch stream around every
+        # bottleneck-conv2 forward (gs_k3_timer_*, include/gaiaseg_hip.h)
+        elapsed_instr = timed_pass(True)
+        import ctypes
+        c_n, c_ms, c_fl = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        lib.check(L.gs_k3_timer_read(ctypes.byref(c_n), ctypes.byref(c_ms), ctypes.byref(c_fl)),
+                  "gs_k3_timer_read")
+        if c_n.value:
+            k3 = (c_n.value, c_ms.value, c_fl.value, elapsed_instr)
+
     if rank == 0:
         imgs = world * bs * args.steps
         out = {
@@ -256,32 +402,43 @@ def main():
                                size[1], size[0], bs, args.arch),
                 "global_batch": world * bs,
                 "parallelism": "dp%d" % world,
+                "allreduce_bytes_per_step_per_rank": int(bytes_per_step),
                 "last_loss": round(loss, 5),
             },
+            "check": check,
         }
         hooks = [h for h in runner.hooks if isinstance(h, ManipulateArchHook)]
         if hooks:
-            out["config"]["archs"] = hooks[0].history[arch_log_start:]
-        if timer is not None:
-            import ctypes
-            c_n, c_ms, c_fl = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
-            lib.check(timer.gs_k3_timer_read(ctypes.byref(c_n), ctypes.byref(c_ms), ctypes.byref(c_fl)),
-                      "gs_k3_timer_read")
-            if c_n.value:
-                launches, ms, flops = c_n.value, c_ms.value, c_fl.value
-                achieved = flops / (ms * 1e-3) / 1e12
-                out["roofline"] = {
-                    "kernel": "igemm_rows_fast_kernel<BM,BN,false,3,0,1> + splitk_reduce_kernel<false,1> (dynamic 3x3 bottleneck conv "
-                              "forward, incl. its split-K reduce where used)",
-                    "bound": "mfma", "achieved": round(achieved, 2),
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": k3_traffic(),
-                    "launches": launches, "avg_launch_us": round(1e3 * ms / launches, 2),
-                    "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
-                }
+            out["config"]["archs"] = hooks[0].history[arch_log_start:arch_log_end]
+        fl = step_flops(model, sampler, args.seed, args.steps, size, bs, fixed_meta) * world
+        out["roofline_step"] = {
+            "what": "all convolutions of the %d timed steps, fwd + dgrad + wgrad (BN / pooling / loss "
+                    "/ SGD carry no credited FLOPs)" % args.steps,
+            "bound": "mfma", "achieved": round(fl / elapsed / 1e12 / world, 2),
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
+            "frac": round(fl / elapsed / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_gflop_per_step_per_gpu": round(fl / args.steps / world / 1e9, 1)}
+        if k3 is not None:
+            launches, ms, flops, el_i = k3
+            achieved = flops / (ms * 1e-3) / 1e12
+            traffic, traffic_src = k3_traffic()
+            out["roofline"] = {
+                "kernel": "igemm_rows_*_kernel<..., KS=3, ROLE=1> (+ its split-K reduce where used): "
+                          "the dynamic 3x3 bottleneck conv forward",
+                "bound": "mfma", "achieved": round(achieved, 2),
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src and "%s (separate rocprofv3 --pmc passes of this "
+                                                  "command)" % traffic_src,
+                "launches": launches, "avg_launch_us": round(1e3 * ms / launches, 2),
+                "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
+                "measured_in": "a separate instrumented pass over the same %d draws (%.3f ms/step; "
+                               "`value` is from the un-instrumented pass)"
+                               % (args.steps, 1e3 * el_i / args.steps),
+            }
         if world == 1 and not args.no_cpu_baseline:
             h, w = (int(v) for v in args.cpu_baseline_size.split("x"))
-            out["cpu_baseline"] = cpu_baseline(cfg, (h, w), args.seed)
+            out["cpu_baseline"] = cpu_baseline(cfg, (h, w), args.seed, bs)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -55,6 +55,7 @@ def train_segmentor(model, train_sampler, val_sampler, dataset, cfg, distributed
     device = torch.device("cuda", torch.cuda.current_device())
     model = model.to(device)
     arena = ParamArena(model)
+    gdist.sync_module_states(model, arena)   # the DDP wrap-time broadcast (:88-96)
     reducer = gdist.GradReducer(arena.flat_grad, arena.segments,
                                 bucket_bytes=cfg.get("bucket_bytes", 64 << 20))
     opt = dict(cfg.optimizer)

@@ -2,7 +2,8 @@
 whose state_dict holds the MAX-size parameters as contiguous OIHW tensors under the reference's
 module names (tools/train_supernet.py:197-202; gaiaseg/apis/train.py:172-175;
 gaiaseg/models/backbones/dynamic_resnet.py:343-345).  The HWIO physical
-layout of this implementation never leaks into a file."""
+layout of this implementation never leaks into a file: `optimizer` holds the SGD momentum per
+parameter NAME in the same logical layout (ParamArena.state_dict)."""
 import os
 
 import torch
@@ -12,10 +13,20 @@ def state_dict_oihw(model):
     return {k: v.detach().cpu().contiguous().clone() for k, v in model.state_dict().items()}
 
 
+def _to_cpu(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj.detach().cpu()
+    if isinstance(obj, dict):
+        return {k: _to_cpu(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_cpu(v) for v in obj)
+    return obj
+
+
 def save_checkpoint(model, filename, optimizer=None, meta=None):
     ck = dict(meta=dict(meta or {}), state_dict=state_dict_oihw(model))
     if optimizer is not None:
-        ck["optimizer"] = {k: v.detach().cpu() for k, v in optimizer.state_dict().items()}
+        ck["optimizer"] = _to_cpu(optimizer.state_dict())
     os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
     torch.save(ck, filename)
 

@@ -46,6 +46,34 @@ def broadcast_object(obj, src=0):
     return box[0]
 
 
+def sync_module_states(model, arena=None, src=0):
+    """The wrap-time broadcast of MMDistributedDataParallel (gaiaseg/apis/train.py:88-96): every
+    rank starts from rank ``src``'s parameters AND buffers.  (``broadcast_buffers=False`` there only
+    disables the per-forward re-broadcast; the reference launch passes no --seed, so without this
+    every rank would train its own random initialisation.)  One broadcast for the parameter arena,
+    one per buffer dtype."""
+    if not is_dist():
+        return
+    with torch.no_grad():
+        if arena is not None:
+            dist.broadcast(arena.flat_param, src=src)
+        else:
+            for p in model.parameters():
+                t = p.data.contiguous()
+                dist.broadcast(t, src=src)
+                p.data.copy_(t)
+        by_dtype = {}
+        for b in model.buffers():
+            by_dtype.setdefault(b.dtype, []).append(b)
+        for bufs in by_dtype.values():
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for b in bufs:
+                b.copy_(flat[off:off + b.numel()].view(b.shape))
+                off += b.numel()
+
+
 _HOST_GROUP = None
 
 

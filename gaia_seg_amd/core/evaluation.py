@@ -84,7 +84,12 @@ class CrossArchEvalHook(Hook):
         self.sampler.set_mode("traverse")
         metas = self.sampler.traverse()
         out = {}
-        saved_key = runner.arch_key
+        # the training subnet must survive the evaluation: with manipulate_arch=False (or a fixed
+        # arch) nobody re-applies it before the next iteration
+        backbone = runner.model.backbone
+        saved = dict(key=runner.arch_key, name=runner.arch_name, meta=runner.arch_meta,
+                     arch={"backbone": {k: v for k, v in backbone.state_dict_of_arch().items()
+                                        if v is not None}})
         for i, meta in enumerate(metas):
             meta = gdist.broadcast_object(meta, src=0)   # :59 broadcast_object(fold_dict(meta))
             runner.model.manipulate_arch(fold_dict(meta)["arch"])
@@ -97,7 +102,9 @@ class CrossArchEvalHook(Hook):
                 (self.logger.info if self.logger else print)(msg)
         self.sampler.set_mode("sample")
         self.results.append((runner.iter + 1, out))
-        runner.arch_key = saved_key
+        runner.model.manipulate_arch(saved["arch"])
+        runner.arch_key, runner.arch_name, runner.arch_meta = saved["key"], saved["name"], saved["meta"]
+        runner.refresh_active()
         return out
 
 

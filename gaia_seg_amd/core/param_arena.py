@@ -49,6 +49,7 @@ class ParamArena:
         self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_mom = torch.zeros(off, dtype=torch.float32, device=dev)
+        self._layout = [(name, p, phys, o, n) for name, p, phys, o, n in layout]
         for name, p, phys, o, n in layout:
             pv = self._view(self.flat_param, p, phys, o, n)
             pv.copy_(p.data)
@@ -105,8 +106,39 @@ class ParamArena:
             _lib.check(L.gs_sgd_step(pb + 4 * a, gb + 4 * a, mb + 4 * a, b - a, lr, momentum,
                                      weight_decay, grad_scale, st), "gs_sgd_step")
 
-    def state_dict(self):
-        return {"momentum": self.flat_mom}
+    def momentum_views(self):
+        """{parameter name: momentum buffer as a LOGICAL (OIHW / plain) view of the flat arena}."""
+        return {name: self._view(self.flat_mom, p, phys, o, n) for name, p, phys, o, n in self._layout}
 
-    def load_state_dict(self, sd):
-        self.flat_mom.copy_(sd["momentum"])
+    def state_dict(self):
+        """Optimizer state keyed by parameter name in the logical layout (contiguous OIHW for conv
+        weights), so that neither the arena offsets nor the physical HWIO layout leak into a
+        checkpoint (tools/train_supernet.py:197-202 stores `optimizer` next to `state_dict`)."""
+        return {"format": "gaia_seg_amd.sgd_momentum.v1",
+                "state": {k: v.detach().clone().contiguous() for k, v in self.momentum_views().items()}}
+
+    def load_state_dict(self, sd, logger=None):
+        """Accepts this build's format; any other optimizer state (e.g. a torch.optim.SGD state_dict
+        of an mmcv checkpoint, whose integer keys carry no parameter names) is skipped with a warning
+        and the momentum restarts from zero."""
+        import warnings
+        state = sd.get("state") if isinstance(sd, dict) else None
+        if not isinstance(sd, dict) or sd.get("format") != "gaia_seg_amd.sgd_momentum.v1" \
+                or not isinstance(state, dict):
+            msg = "optimizer state of a foreign format: momentum buffers restart from zero"
+            (logger.warning if logger is not None else warnings.warn)(msg)
+            return False
+        views = self.momentum_views()
+        missing = [k for k in views if k not in state]
+        with torch.no_grad():
+            for k, v in state.items():
+                if k in views:
+                    if tuple(views[k].shape) != tuple(v.shape):
+                        raise RuntimeError("momentum of %s: checkpoint %s vs model %s"
+                                           % (k, tuple(v.shape), tuple(views[k].shape)))
+                    views[k].copy_(v)
+        if missing:
+            msg = "optimizer state lacks %d parameters (e.g. %s): their momentum is zero" % (
+                len(missing), missing[0])
+            (logger.warning if logger is not None else warnings.warn)(msg)
+        return True

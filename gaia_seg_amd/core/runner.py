@@ -142,9 +142,11 @@ class IterBasedRunner:
         self.hooks = []
         self.outputs = None
         self.arch_name = "supernet"
-        self.active_params = None
-        self.active_ranges = None
+        self.active_params = None      # parameters the current subnet uses
+        self.trainable_params = None   # ... of those, the ones that receive gradients / updates
+        self.active_ranges = None      # merged arena ranges of trainable_params
         self.arch_key = None
+        self.arch_meta = None
         # GS_HOST_PROF=1: accumulate host-side seconds per phase of train_iter (diagnostics)
         self.host_prof = {} if os.environ.get("GS_HOST_PROF") else None
         self.set_arch(None)
@@ -166,10 +168,20 @@ class IterBasedRunner:
             self.model.manipulate_arch(fold_dict(meta)["arch"])
             self.arch_name = meta.get("name", "random")
             self.arch_key = arch_key(meta)
+            self.arch_meta = meta
         else:
             self.arch_key = ("current",)
+        self.refresh_active()
+
+    def refresh_active(self):
+        """Recompute the active parameter sets from the model's CURRENT arch state.  Frozen
+        parameters (frozen_stages / frozen_layers / norm_cfg requires_grad=False) are left out of
+        the zero / all-reduce / SGD ranges: torch.optim.SGD skips parameters without a gradient,
+        so they must neither decay nor move (gaiaseg/models/backbones/dynamic_resnet.py:304-334)."""
         self.active_params = self.model.active_parameters()
-        self.active_ranges = self.arena.ranges_for(self.active_params, self.arch_key)
+        self.trainable_params = [p for p in self.active_params if p.requires_grad]
+        key = self.arch_key if self.arch_key != ("current",) else None
+        self.active_ranges = self.arena.ranges_for(self.trainable_params, key)
 
     def train_iter(self, data_batch):
         prof = self.host_prof
@@ -179,7 +191,8 @@ class IterBasedRunner:
         self.call_hook("before_train_iter")
         t1 = time.perf_counter() if prof is not None else 0.0
         self.arena.zero_grad(self.active_ranges)
-        self.reducer.begin(self.active_params, self.arch_key)
+        self.reducer.begin(self.trainable_params,
+                           self.arch_key if self.arch_key != ("current",) else None)
         t2 = time.perf_counter() if prof is not None else 0.0
         self.outputs = self.model.train_step(data_batch, None)
         t3 = time.perf_counter() if prof is not None else 0.0
@@ -211,7 +224,7 @@ class IterBasedRunner:
         from .checkpoint import load_checkpoint
         ck = load_checkpoint(self.model, checkpoint, strict=True)
         if "optimizer" in ck:
-            self.arena.load_state_dict(ck["optimizer"])
+            self.arena.load_state_dict(ck["optimizer"], logger=self.logger)
         self.iter = ck.get("meta", {}).get("iter", 0)
 
     def load_checkpoint(self, checkpoint):

@@ -140,6 +140,16 @@ class KernelTimer:
 
 TIMER = None  # set to a KernelTimer to enable
 
+# Diagnostics: when set to a list, every BatchNorm(+residual)+ReLU records (gamma Parameter,
+# bool NHWC tensor "output > 0", taken at once: UPer's top-down add later updates outputs in place).  The gradient-parity tests use it to evaluate the CPU
+# oracle on the same ReLU branch pattern as this path (tests/conftest.py).  None = off (no cost).
+RELU_TRACE = None
+
+
+def _trace_relu(bn, out):
+    if RELU_TRACE is not None and bn.weight is not None:
+        RELU_TRACE.append((bn.weight, out.t > 0))
+
 
 def conv2d(tape, x, weight, bias, co, stride=1, pad=0, dil=1, out=None, tag=None):
     """DynConv2d forward: y = conv(x, weight[:co, :x.C]) (+ bias[:co]).
@@ -334,6 +344,8 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
                              residual.ptr if residual is not None else None,
                              residual.ld if residual is not None else 0, 1 if relu else 0,
                              out.ptr, out.ld, st), "gs_bn_apply")
+    if relu:
+        _trace_relu(bn, out)
 
     def backward():
         dy = out.g
@@ -353,22 +365,31 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
                                       bsums.data_ptr(), wsb.data_ptr(), wsb.numel(), s),
                    "gs_bn_bwd_reduce")
         bcount = count
-        if use_batch and bn.process_group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(bsums, group=bn.process_group)
-        mask_apply = 0 if want_g else mask  # dy already masked in place
         wgrad = bn.weight is not None and bn.weight.requires_grad
         bgrad = bn.bias is not None and bn.bias.requires_grad
         gw = ensure_grad(bn.weight) if wgrad else None
         gb = ensure_grad(bn.bias) if bgrad else None
+        synced = use_batch and bn.process_group is not None
+        if synced:
+            # dx needs the GROUP sums (torch.nn.SyncBatchNorm backward); dgamma / dbeta are this
+            # rank's own sums -- the data-parallel gradient all-reduce adds the ranks up afterwards.
+            # Writing the group sums there would count every rank world_size times.
+            import torch.distributed as dist
+            if wgrad:
+                gw[:C].copy_(bsums[C:2 * C])
+            if bgrad:
+                gb[:C].copy_(bsums[:C])
+            dist.all_reduce(bsums, group=bn.process_group)
+        mask_apply = 0 if want_g else mask  # dy already masked in place
         if x.g is not None:
             raise RuntimeError("BN input has more than one consumer; unsupported")
         x.new_grad() if x.parent is None else _alloc_parent_grad(x)
         _lib.check(L.gs_bn_bwd_apply(dy.data_ptr(), dy.stride(2), x.ptr, x.ld, out.ptr, out.ld,
                                      rows, C, coeffs_ptr, bsums.data_ptr(), bcount,
                                      mask_apply, 1 if use_batch else 0, x.g.data_ptr(),
-                                     x.g.stride(2), gw.data_ptr() if wgrad else None,
-                                     gb.data_ptr() if bgrad else None, s), "gs_bn_bwd_apply")
+                                     x.g.stride(2), gw.data_ptr() if (wgrad and not synced) else None,
+                                     gb.data_ptr() if (bgrad and not synced) else None, s),
+                   "gs_bn_bwd_apply")
         if wgrad:
             _notify(bn.weight)
         if bgrad:
@@ -437,6 +458,8 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
                                     current_stream_ptr()), "gs_conv_bn_forward")
     if use_batch and bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked()
+    if relu:
+        _trace_relu(bn, out)
 
     def backward():
         dz = out.g

@@ -21,6 +21,23 @@ import torch.nn as nn
 from . import ops as O
 
 
+def _key(bn):
+    """Name of the BatchNorm a ReLU follows (every ReLU on this path follows one): the key under
+    which oracle.ops.relu records / is given that ReLU's mask.  Set by OEncoderDecoder."""
+    return getattr(bn, "_gs_name", None)
+
+
+class OReLU(nn.Module):
+    """nn.ReLU(inplace=True) of the deep stem (dynamic_resnet.py:258-288), keyed by its BN."""
+
+    def __init__(self, bn):
+        super().__init__()
+        self._bn = [bn]   # not a submodule: keeps the Sequential indices / state_dict unchanged
+
+    def forward(self, x):
+        return O.relu(x, key=_key(self._bn[0]))
+
+
 class OConv(nn.Conv2d):
     """DynConv2d (A1): max-size nn.Conv2d parameters, forward on the leading slice."""
 
@@ -61,7 +78,7 @@ class OConvModule(nn.Module):
         if self.with_norm:
             x = self.bn(x)
         if self.with_act:
-            x = torch.relu(x)
+            x = O.relu(x, key=_key(self.bn) if self.with_norm else None)
         return x
 
 
@@ -89,12 +106,12 @@ class OBottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = torch.relu(self.bn1(self.conv1(x)))
-        out = torch.relu(self.bn2(self.conv2(out)))
+        out = O.relu(self.bn1(self.conv1(x)), key=_key(self.bn1))
+        out = O.relu(self.bn2(self.conv2(out)), key=_key(self.bn2))
         out = self.bn3(self.conv3(out))
         if self.downsample is not None:
             identity = self.downsample(x)
-        return torch.relu(out + identity)
+        return O.relu(out + identity, key=_key(self.bn3))
 
 
 class OResLayer(nn.ModuleList):
@@ -125,13 +142,11 @@ class ODynamicResNet(nn.Module):
         self.out_indices = out_indices
         if deep_stem:  # dynamic_resnet.py:258-288
             sw = stem_width
+            b0, b1, b2 = OBN(sw[0]), OBN(sw[1]), OBN(sw[2])
             self.stem = nn.Sequential(
-                OConv(in_channels, sw[0], 3, stride=2, padding=1, bias=False), OBN(sw[0]),
-                nn.ReLU(inplace=True),
-                OConv(sw[0], sw[1], 3, stride=1, padding=1, bias=False), OBN(sw[1]),
-                nn.ReLU(inplace=True),
-                OConv(sw[1], sw[2], 3, stride=1, padding=1, bias=False), OBN(sw[2]),
-                nn.ReLU(inplace=True))
+                OConv(in_channels, sw[0], 3, stride=2, padding=1, bias=False), b0, OReLU(b0),
+                OConv(sw[0], sw[1], 3, stride=1, padding=1, bias=False), b1, OReLU(b1),
+                OConv(sw[1], sw[2], 3, stride=1, padding=1, bias=False), b2, OReLU(b2))
             inplanes = sw[-1]
         else:  # :290-301
             self.conv1 = OConv(in_channels, stem_width, 7, stride=2, padding=3, bias=False)
@@ -171,7 +186,7 @@ class ODynamicResNet(nn.Module):
         if self.deep_stem:
             x = self.stem(x)
         else:
-            x = torch.relu(self.bn1(self.conv1(x)))
+            x = O.relu(self.bn1(self.conv1(x)), key=_key(self.bn1))
         x = self.maxpool(x)
         outs = []
         for i, name in enumerate(self.res_layers):
@@ -322,6 +337,9 @@ class OEncoderDecoder(nn.Module):
         self.backbone = ODynamicResNet(**b)
         self.decode_head = _build_head(decode_head)
         self.auxiliary_head = _build_head(auxiliary_head) if auxiliary_head is not None else None
+        for name, m in self.named_modules():
+            if isinstance(m, OBN):
+                m._gs_name = name
 
     def manipulate_arch(self, arch):
         if "backbone" in arch:

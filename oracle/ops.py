@@ -33,6 +33,74 @@ def dyn_batch_norm(x, running_mean, running_var, weight, bias, training, momentu
     return F.batch_norm(x, rm, rv, w, b, training or rm is None, momentum, eps)
 
 
+# ---- ReLU with an optional externally supplied mask (gradient-parity instrument) ---------------
+class ReluMasks:
+    """Context for `relu(x, key)`: every ReLU of the model path follows a BatchNorm, `key` is that
+    BN's module name.
+
+    Why: two correct fp32 implementations can disagree on the sign of a pre-activation that is
+    within rounding of zero; that single ReLU branch flip changes every upstream gradient by a
+    finite amount (tests/test_grad_criterion.py demonstrates it), so gradients of the HIP path and of
+    this restatement can only be compared tightly on the SAME branch pattern.  With `masks` given
+    (key -> bool tensor, the HIP path's `z > 0`), relu(x) = x * mask: the function is then smooth
+    around the evaluation point and gradients must agree to rounding.  Every position where the
+    given mask differs from this side's own `x > 0` is recorded with |x| relative to the tensor's
+    RMS, so the test can REQUIRE that disagreements occur only within rounding of zero.
+    With masks=None the context only records this side's own masks (self.own)."""
+
+    def __init__(self, masks=None, keep_own=False):
+        self.masks = masks
+        self.keep_own = keep_own
+        self.own = {}
+        self.pre = {}          # keep_own: the pre-activations themselves
+        self.flips = {}        # key -> (count, max |x| / rms(x) over the flipped positions)
+        self.used = set()
+
+    def apply(self, x, key):
+        own = x.detach() > 0
+        if self.keep_own:
+            self.own[key] = own
+            self.pre[key] = x.detach()
+        if self.masks is None:
+            return torch.relu(x)
+        if key not in self.masks:
+            raise KeyError("no ReLU mask supplied for %r" % key)
+        if key in self.used:
+            raise RuntimeError("ReLU key %r used twice in one forward" % key)
+        self.used.add(key)
+        m = self.masks[key]
+        if m.shape != x.shape:
+            raise ValueError("mask %s vs activation %s at %r" % (tuple(m.shape), tuple(x.shape), key))
+        diff = own != m
+        n = int(diff.sum())
+        if n:
+            xd = x.detach()
+            rms = float(xd.double().pow(2).mean().sqrt().clamp_min(1e-30))
+            self.flips[key] = (n, float(xd[diff].abs().max()) / rms)
+        return x * m.to(x.dtype)
+
+    def __enter__(self):
+        global _RELU_CTX
+        self._prev = _RELU_CTX
+        _RELU_CTX = self
+        return self
+
+    def __exit__(self, *exc):
+        global _RELU_CTX
+        _RELU_CTX = self._prev
+        return False
+
+
+_RELU_CTX = None
+
+
+def relu(x, key=None):
+    """torch.relu, or the masked form when a ReluMasks context is active and the call is keyed."""
+    if _RELU_CTX is None or key is None:
+        return torch.relu(x)
+    return _RELU_CTX.apply(x, key)
+
+
 # ---- mmseg.ops.resize == F.interpolate: call sites dynamic_fcn_head.py:141-145 -----------------
 def resize(input, size=None, scale_factor=None, mode="nearest", align_corners=None):
     return F.interpolate(input, size, scale_factor, mode, align_corners)

@@ -23,16 +23,3 @@ def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
-
-
-def l2_err(a, b):
-    """||a-b||_2 / ||b||_2 on CPU float64.  Used for gradients: a ReLU whose pre-activation is
-    within rounding of zero can take a different branch in two correct fp32 implementations, which
-    changes single gradient elements by O(1) (measured on the MI355X: 1 flip in 80000 elements of
-    one head layer moved the max-norm error of every upstream gradient to 1e-2 while every kernel
-    matched torch to 3e-7 on the same device data).  The L2 norm is insensitive to such isolated
-    flips; forward quantities (loss, logits, features, BN statistics) are still checked in the
-    max norm at the 1e-3 tolerance BASELINE.json states."""
-    a = a.detach().double().cpu()
-    b = b.detach().double().cpu()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))

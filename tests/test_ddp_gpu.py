@@ -23,14 +23,15 @@ def _free_port():
     return p
 
 
-def _build(head_norm):
+def _build(head_norm, seed=0, backbone_norm=None):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util_models import fcn_head, model_cfg, psp_head
     from gaia_seg_amd.models import build_segmentor
-    cfg = model_cfg(psp_head(), aux=True)
+    cfg = model_cfg(psp_head(), aux=True) if backbone_norm is None else \
+        model_cfg(psp_head(), aux=True, norm=backbone_norm)
     for h in ("decode_head", "auxiliary_head"):
         cfg[h]["norm_cfg"] = dict(type=head_norm, requires_grad=True)
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     return build_segmentor(cfg)
 
 
@@ -39,7 +40,9 @@ def _runner(model, lr=0.05):
     from gaia_seg_amd.core.param_arena import ParamArena
     from gaia_seg_amd.core.runner import ArenaOptimizerHook, IterBasedRunner, ManipulateArchHook
     from gaia_seg_amd.core.model_space import build_model_sampler
+    from gaia_seg_amd.core import dist as gdist
     arena = ParamArena(model)
+    gdist.sync_module_states(model, arena)
     runner = IterBasedRunner(model, arena, GradReducer(arena.flat_grad, arena.segments, bucket_bytes=1 << 20),
                              base_lr=lr, momentum=0.9, weight_decay=5e-4, max_iters=100)
     sampler = build_model_sampler(dict(type="anchor", anchors=[
@@ -53,29 +56,41 @@ def _runner(model, lr=0.05):
     return runner, arena
 
 
-def _worker(rank, world, port, head_norm, q):
+def _norm_checksum(model):
+    """(sum, abs-sum) over the BatchNorm gamma / beta only: sensitive to their gradients' scale."""
+    from torch.nn.modules.batchnorm import _BatchNorm
+    s = a = 0.0
+    for m in model.modules():
+        if isinstance(m, _BatchNorm):
+            for p in (m.weight, m.bias):
+                s += p.detach().double().sum().item()
+                a += (p.detach().double() - (1.0 if p is m.weight else 0.0)).abs().sum().item()
+    return s, a
+
+
+def _worker(rank, world, port, head_norm, q, seed_per_rank=False, backbone_norm=None, steps=3):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from gaia_seg_amd.core.synthetic import make_batch
-    model = _build(head_norm).cuda().train()
+    model = _build(head_norm, seed=rank if seed_per_rank else 0, backbone_norm=backbone_norm).cuda().train()
     runner, arena = _runner(model)
     names = []
-    for it in range(3):
+    for it in range(steps):
         batch = make_batch(2, 64, 96, seed=100 * it + rank, device="cuda", border=2)
         out = runner.train_iter(batch)
         names.append(runner.arch_name)
     torch.cuda.synchronize()
     q.put((rank, arena.flat_param.double().sum().item(), arena.flat_param.abs().double().sum().item(),
-           names, float(out["log_vars"]["loss"]), runner.reducer.bytes_reduced))
+           names, float(out["log_vars"]["loss"]), runner.reducer.bytes_reduced, _norm_checksum(model)))
     dist.destroy_process_group()
 
 
-def _spawn(head_norm):
+def _spawn(head_norm, **kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, head_norm, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, head_norm, q), kwargs=kw) for r in range(2)]
     for p in procs:
         p.start()
     out = sorted(q.get(timeout=300) for _ in procs)
@@ -121,3 +136,37 @@ def test_two_rank_step_equals_gradient_average():
     ref_abs = arena.flat_param.abs().double().sum().item()
     assert hook.history == r0[3]
     assert abs(ref_sum - r0[1]) <= 1e-6 * ref_abs and abs(ref_abs - r0[2]) <= 1e-6 * ref_abs
+
+
+def test_ranks_built_from_different_seeds_start_from_rank0_weights():
+    """The reference launch passes no --seed: MMDistributedDataParallel's wrap-time broadcast makes
+    the replicas equal (gaiaseg/apis/train.py:88-96).  Here: sync_module_states."""
+    r0, r1 = _spawn("SyncBN", seed_per_rank=True)
+    assert r0[1] == r1[1] and r0[2] == r1[2]
+    ref, _ = _spawn("SyncBN")                             # both ranks seeded like rank 0
+    assert r0[1] == ref[1] and r0[2] == ref[2]
+
+
+def test_two_rank_syncbn_equals_one_process_on_the_concatenated_batch():
+    """With every BatchNorm synchronised over the world, 2 ranks x bs 2 is the same function as one
+    process on the 4 images: global batch statistics, mean of the two per-rank losses = loss of the
+    concatenation (equal sizes), gradients averaged.  Pins the VALUES of the SyncBN gamma / beta
+    gradients (torch.nn.SyncBatchNorm + DDP: (1/world) * sum of the per-rank sums)."""
+    r0, _ = _spawn("SyncBN", backbone_norm="SyncBN", steps=2)
+    from gaia_seg_amd.core.synthetic import make_batch
+    model = _build("SyncBN", backbone_norm="SyncBN").cuda().train()
+    runner, arena = _runner(model)
+    for it in range(2):
+        parts = [make_batch(2, 64, 96, seed=100 * it + rank, device="cuda", border=2) for rank in range(2)]
+        batch = dict(img=torch.cat([p["img"] for p in parts]),
+                     gt_semantic_seg=torch.cat([p["gt_semantic_seg"] for p in parts]),
+                     img_metas=parts[0]["img_metas"] + parts[1]["img_metas"])
+        runner.train_iter(batch)
+    torch.cuda.synchronize()
+    ref_sum = arena.flat_param.double().sum().item()
+    ref_abs = arena.flat_param.abs().double().sum().item()
+    assert runner.hooks[0].history == r0[3]
+    assert abs(ref_sum - r0[1]) <= 2e-6 * ref_abs and abs(ref_abs - r0[2]) <= 2e-6 * ref_abs
+    ns, na = _norm_checksum(model)      # na = total distance the BN affine parameters moved
+    assert na > 1e-3
+    assert abs(ns - r0[6][0]) <= 1e-3 * na and abs(na - r0[6][1]) <= 1e-3 * na

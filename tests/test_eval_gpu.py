@@ -42,10 +42,13 @@ def test_cross_arch_eval_hook_matches_oracle(hip_lib):
                         "arch.backbone.body.depth": a["body"]["depth"]})
     sampler = build_model_sampler(dict(type="anchor", anchors=anchors))
 
-    class R:
-        model, iter, arch_key = prod, 0, None
+    from gaia_seg_amd.core.dist import GradReducer
+    from gaia_seg_amd.core.param_arena import ParamArena
+    from gaia_seg_amd.core.runner import IterBasedRunner
+    arena = ParamArena(prod)
+    runner = IterBasedRunner(prod, arena, GradReducer(arena.flat_grad, arena.segments))
     hook = CrossArchEvalHook(batches, sampler, interval=1, num_batches=2)
-    out = hook.evaluate(R())
+    out = hook.evaluate(runner)
     orc.eval()
     for name in ("sub", "max"):
         orc.manipulate_arch(arch_meta(name))

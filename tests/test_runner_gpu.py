@@ -1,0 +1,151 @@
+"""Training-loop state on the GPU: frozen parameters, the subnet after a cross-arch evaluation,
+optimizer state in checkpoints (r01 advisor findings, each with the reference behaviour it must
+match)."""
+import copy
+import os
+
+import pytest
+import torch
+
+from util_models import arch_meta, fcn_head, make_batch, model_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _runner(model, **kw):
+    from gaia_seg_amd.core.dist import GradReducer
+    from gaia_seg_amd.core.param_arena import ParamArena
+    from gaia_seg_amd.core.runner import ArenaOptimizerHook, IterBasedRunner
+    arena = ParamArena(model)
+    runner = IterBasedRunner(model, arena, GradReducer(arena.flat_grad, arena.segments), base_lr=0.05,
+                             momentum=0.9, weight_decay=5e-4, max_iters=100, **kw)
+    runner.register_hook(ArenaOptimizerHook())
+    return runner, arena
+
+
+def _batch(seed=0):
+    img, gt = make_batch(2, 64, 96, seed=seed)
+    metas = [dict(ori_shape=(64, 96, 3), img_shape=(64, 96, 3), flip=False) for _ in range(2)]
+    return dict(img=img.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda())
+
+
+def _anchor(name):
+    a = arch_meta(name)["backbone"]
+    return {"name": name, "arch.backbone.stem.width": a["stem"]["width"],
+            "arch.backbone.body.width": a["body"]["width"], "arch.backbone.body.depth": a["body"]["depth"]}
+
+
+def test_frozen_stages_are_bit_unchanged_by_training(hip_lib):
+    """frozen_stages=1 (gaiaseg/models/backbones/dynamic_resnet.py:304-321): stem + layer1 have
+    requires_grad False and eval-mode BN.  torch.optim.SGD skips parameters without a gradient, so
+    neither weight decay nor momentum may touch them, and their BN statistics must not move."""
+    from gaia_seg_amd.models import build_segmentor
+    cfg = copy.deepcopy(model_cfg(fcn_head(), aux=True))
+    cfg["backbone"]["frozen_stages"] = 1
+    torch.manual_seed(0)
+    model = build_segmentor(cfg).cuda().train()
+    runner, arena = _runner(model)
+    runner.set_arch(_anchor("sub"))
+    frozen = {k: v.detach().clone() for k, v in model.state_dict().items()
+              if k.startswith(("backbone.conv1", "backbone.bn1", "backbone.layer1"))}
+    others = {k: v.detach().clone() for k, v in model.state_dict().items()
+              if k.startswith("backbone.layer2.0.conv1")}
+    assert frozen and others
+    for it in range(3):
+        runner.train_iter(_batch(it))
+    torch.cuda.synchronize()
+    sd = model.state_dict()
+    for k, v in frozen.items():
+        assert torch.equal(sd[k], v), "frozen tensor %s changed" % k
+    for k, v in others.items():
+        assert not torch.equal(sd[k], v), "trainable tensor %s did not move" % k
+    # the frozen segments are outside the zero / all-reduce / SGD ranges
+    covered = set()
+    for a, b in runner.active_ranges:
+        covered.update(range(a, b, 64))
+    for n, p in model.named_parameters():
+        o, _ = arena.segments[id(p)]
+        if n.startswith(("backbone.conv1", "backbone.bn1", "backbone.layer1.")):
+            assert o not in covered, n
+
+
+def test_eval_hook_leaves_the_training_subnet_in_place(hip_lib):
+    """CrossArchEvalHook.evaluate walks the val anchors; afterwards the model, the active ranges and
+    the reducer plan must again be those of the subnet that was training (manipulate_arch=False
+    runs never re-apply it)."""
+    from gaia_seg_amd.core.evaluation import CrossArchEvalHook
+    from gaia_seg_amd.core.model_space import build_model_sampler
+    from gaia_seg_amd.models import build_segmentor
+    torch.manual_seed(0)
+    model = build_segmentor(copy.deepcopy(model_cfg(fcn_head(), aux=True))).cuda().train()
+    runner, arena = _runner(model)
+    runner.set_arch(_anchor("sub"))
+    ranges0 = list(runner.active_ranges)
+    state0 = copy.deepcopy(model.backbone.state_dict_of_arch())
+    sampler = build_model_sampler(dict(type="anchor", anchors=[_anchor("min"), _anchor("max")]))
+    hook = CrossArchEvalHook([_batch(5)], sampler, interval=1, num_batches=1)
+    hook.evaluate(runner)
+    assert model.backbone.state_dict_of_arch() == state0
+    assert runner.active_ranges == ranges0 and runner.arch_name == "sub"
+    assert model.training
+    # and a following step trains exactly the subnet: layer3.2 (depth 2 in 'sub') stays untouched
+    before = model.backbone.layer3[2].conv1.weight.detach().clone()
+    runner.train_iter(_batch(6))
+    torch.cuda.synchronize()
+    assert torch.equal(model.backbone.layer3[2].conv1.weight, before)
+
+    # same with a run that never called set_arch(meta): the state, not the meta, is restored
+    model.manipulate_arch(arch_meta("min"))
+    runner.arch_meta, runner.arch_key = None, ("current",)
+    runner.refresh_active()
+    ranges1 = list(runner.active_ranges)
+    hook.evaluate(runner)
+    assert runner.active_ranges == ranges1
+    assert model.backbone.state_dict_of_arch()["body"]["depth"] == arch_meta("min")["backbone"]["body"]["depth"]
+
+
+def test_checkpoint_keeps_momentum_by_name_in_oihw(hip_lib, tmp_path):
+    """`optimizer` in a checkpoint is keyed by parameter name in the logical layout; a foreign
+    optimizer state (torch.optim.SGD of an mmcv checkpoint) is tolerated on resume."""
+    from gaia_seg_amd.core.checkpoint import save_checkpoint
+    from gaia_seg_amd.models import build_segmentor
+    torch.manual_seed(0)
+    cfg = model_cfg(fcn_head(), aux=True)
+    model = build_segmentor(copy.deepcopy(cfg)).cuda().train()
+    runner, arena = _runner(model)
+    runner.set_arch(_anchor("max"))
+    for it in range(2):
+        runner.train_iter(_batch(it))
+    path = os.path.join(str(tmp_path), "iter_2.pth")
+    save_checkpoint(model, path, optimizer=arena, meta=dict(iter=2))
+    ck = torch.load(path, map_location="cpu")
+    mom = ck["optimizer"]["state"]
+    w = model.backbone.layer2[0].conv2.weight
+    assert tuple(mom["backbone.layer2.0.conv2.weight"].shape) == tuple(w.shape)      # OIHW
+    assert mom["backbone.layer2.0.conv2.weight"].is_contiguous()
+    assert float(mom["backbone.layer2.0.conv2.weight"].abs().max()) > 0
+
+    torch.manual_seed(1)
+    model2 = build_segmentor(copy.deepcopy(cfg)).cuda().train()
+    runner2, arena2 = _runner(model2)
+    runner2.resume(path)
+    assert runner2.iter == 2
+    assert torch.equal(arena2.flat_mom, arena.flat_mom)
+    assert torch.equal(arena2.flat_param, arena.flat_param)
+    # both continue identically
+    runner2.set_arch(_anchor("max"))
+    runner.train_iter(_batch(9))
+    runner2.train_iter(_batch(9))
+    torch.cuda.synchronize()
+    assert torch.equal(arena2.flat_param, arena.flat_param)
+
+    # a torch.optim.SGD state_dict (integer keys, no names) must not break resume
+    ck["optimizer"] = {"state": {0: {"momentum_buffer": torch.zeros(3)}},
+                       "param_groups": [{"lr": 0.01, "params": [0]}]}
+    foreign = os.path.join(str(tmp_path), "foreign.pth")
+    torch.save(ck, foreign)
+    model3 = build_segmentor(copy.deepcopy(cfg)).cuda().train()
+    runner3, arena3 = _runner(model3)
+    with pytest.warns(UserWarning):
+        runner3.resume(foreign)
+    assert float(arena3.flat_mom.abs().max()) == 0.0
