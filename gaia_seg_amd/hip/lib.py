@@ -48,6 +48,12 @@ class CeDesc(Structure):
                 ("l_sc", c_int64), ("ignore_index", c_int32), ("align_corners", c_int32)]
 
 
+class SlideDesc(Structure):
+    """Mirror of ``gs_slide_desc``."""
+    _fields_ = [(k, c_int32) for k in ("N", "C", "ld", "hl", "wl", "hc", "wc", "H", "W", "Ho", "Wo",
+                                       "ny", "nx", "align_corners", "flip", "reserved")]
+
+
 _P = c_void_p  # device pointers and the stream travel as plain addresses
 _i32, _i64, _f32, _f64, _sz = c_int32, c_int64, c_float, c_double, c_size_t
 _CD, _CE, _BN = POINTER(ConvDesc), POINTER(CeDesc), POINTER(BnArgs)
@@ -100,6 +106,7 @@ PROTOTYPES = {
     "gs_ce_backward_ws": (_i32, [_CE, _P, _P, _P, _P, _P, _f32, _P, _i32, _P, _sz, _P]),
     "gs_ce_label_prob": (_i32, [_CE, _P, _P, _P, _P]),
     "gs_resize_argmax": (_i32, [_CE, _P, _P, _P, _P]),
+    "gs_slide_fuse": (_i32, [POINTER(SlideDesc), POINTER(_i32), POINTER(_i32), _P, _P, _P, _P, _P]),
     "gs_ohem_workspace_bytes": (_sz, []),
     "gs_ohem_weights": (_i32, [_P, _i64, _i64, _f32, _i32, _P, _P, _sz, _P]),
     "gs_confusion_matrix": (_i32, [_P, _P, _i64, _i32, _i32, _P, _P]),

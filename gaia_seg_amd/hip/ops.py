@@ -144,6 +144,7 @@ TIMER = None  # set to a KernelTimer to enable
 # bool NHWC tensor "output > 0", taken at once: UPer's top-down add later updates outputs in place).  The gradient-parity tests use it to evaluate the CPU
 # oracle on the same ReLU branch pattern as this path (tests/conftest.py).  None = off (no cost).
 RELU_TRACE = None
+POOL_TRACE = None   # same, for MaxPool2d: list of uint8 [N, Ho, Wo, C] argmax tap tensors (kh * k + kw)
 
 
 def _trace_relu(bn, out):
@@ -530,6 +531,8 @@ def maxpool(tape, x, k=3, s=2, p=1):
     _lib.check(L.gs_maxpool_forward(x.ptr, x.N, x.H, x.W, x.C, x.ld, k, s, p, ho, wo, out.ptr,
                                     out.ld, idx.data_ptr(), current_stream_ptr()),
                "gs_maxpool_forward")
+    if POOL_TRACE is not None:
+        POOL_TRACE.append(idx)
 
     def backward():
         dy = out.g

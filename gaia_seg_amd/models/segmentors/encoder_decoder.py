@@ -135,109 +135,77 @@ class EncoderDecoder(nn.Module):
             losses.update(self._auxiliary_head_forward_train(x, img_metas, gt_semantic_seg))
         return losses
 
-    # ---- inference (dynamic_distiller.py:416-521) ----
-    def slide_inference(self, img, img_meta, rescale):
-        h_stride, w_stride = self.test_cfg.stride
-        h_crop, w_crop = self.test_cfg.crop_size
-        batch_size, _, h_img, w_img = img.size()
-        num_classes = self.num_classes
-        h_grids = max(h_img - h_crop + h_stride - 1, 0) // h_stride + 1
-        w_grids = max(w_img - w_crop + w_stride - 1, 0) // w_stride + 1
-        preds = img.new_zeros((batch_size, num_classes, h_img, w_img))
-        count_mat = img.new_zeros((batch_size, 1, h_img, w_img))
-        for h_idx in range(h_grids):
-            for w_idx in range(w_grids):
-                y1 = h_idx * h_stride
-                x1 = w_idx * w_stride
-                y2 = min(y1 + h_crop, h_img)
-                x2 = min(x1 + w_crop, w_img)
-                y1 = max(y2 - h_crop, 0)
-                x1 = max(x2 - w_crop, 0)
-                crop_img = img[:, :, y1:y2, x1:x2].contiguous()
-                crop_seg_logit = self.encode_decode(crop_img, img_meta)
-                preds[:, :, y1:y2, x1:x2] += crop_seg_logit
-                count_mat[:, :, y1:y2, x1:x2] += 1
-        assert (count_mat == 0).sum() == 0
-        preds = preds / count_mat
-        if rescale:
-            preds = self._resize_logits(preds, img_meta[0]["ori_shape"][:2])
-        return preds
+    # ---- test time: one fused epilogue kernel per view (core/inference.py, csrc/inference.hip) ----
+    def _fused(self):
+        from ...core.inference import FusedInference
+        eng = getattr(self, "_fused_engine", None)
+        if eng is None or eng.num_classes != self.num_classes or eng.align_corners != bool(self.align_corners):
+            eng = FusedInference(self.num_classes, self.align_corners)
+            self._fused_engine = eng
+        return eng
 
-    def whole_inference(self, img, img_meta, rescale):
-        seg_logit = self.encode_decode(img, img_meta)
-        if rescale and tuple(seg_logit.shape[2:]) != tuple(img_meta[0]["ori_shape"][:2]):
-            seg_logit = self._resize_logits(seg_logit, img_meta[0]["ori_shape"][:2])
-        return seg_logit
+    def _view(self, img, img_meta, rescale, probs_in=None, want_probs=False, want_labels=True):
+        """Epilogue of ONE (possibly flipped) view: window logits -> accumulate / normalise / rescale
+        -> softmax -> flip back -> (+ probs_in) -> argmax.  Semantics of the reference's `inference`
+        (dynamic_distiller.py:475-508) with slide / whole mode from ``test_cfg``."""
+        meta0 = img_meta[0]
+        ori = meta0["ori_shape"]
+        if any(m["ori_shape"] != ori for m in img_meta):
+            raise ValueError("all images of a test batch must share ori_shape")
+        mode = self.test_cfg.mode
+        kw = {}
+        if mode == "slide":
+            kw = dict(crop_size=self.test_cfg.crop_size, stride=self.test_cfg.stride)
+        flip = meta0.get("flip_direction", "horizontal") if meta0.get("flip", False) else None
+        if flip not in (None, "horizontal", "vertical"):
+            raise ValueError("flip_direction must be 'horizontal' or 'vertical', got %r" % (flip,))
+
+        def logits_fn(batch):
+            return self._decode_head_forward_test(self.extract_feat(batch), img_meta)
+        return self._fused()(logits_fn, img, mode=mode, out_size=tuple(ori[:2]) if rescale else None,
+                             flip=flip, probs_in=probs_in, want_probs=want_probs,
+                             want_labels=want_labels, **kw)
 
     def inference(self, img, img_meta, rescale):
-        assert self.test_cfg.mode in ["slide", "whole"]
-        ori_shape = img_meta[0]["ori_shape"]
-        assert all(_["ori_shape"] == ori_shape for _ in img_meta)
-        if self.test_cfg.mode == "slide":
-            seg_logit = self.slide_inference(img, img_meta, rescale)
-        else:
-            seg_logit = self.whole_inference(img, img_meta, rescale)
-        output = torch.softmax(seg_logit, dim=1)
-        flip = img_meta[0].get("flip", False)
-        if flip:
-            flip_direction = img_meta[0]["flip_direction"]
-            assert flip_direction in ["horizontal", "vertical"]
-            output = output.flip(dims=(3,)) if flip_direction == "horizontal" else output.flip(dims=(2,))
-        return output
+        """Class probabilities [N, C, H, W] of one view (the tensor the reference's API returns)."""
+        return self._view(img, img_meta, rescale, want_probs=True, want_labels=False)[1]
 
-    def _whole_argmax(self, img, img_meta, rescale):
-        """whole_inference + softmax + argmax in one fused kernel: argmax of the bilinearly resized
-        logits straight from the low-resolution head output (softmax is monotone; the 19xHxW
-        tensor never exists).  Valid when the two resizes of the reference (to the input size, then
-        to ori_shape, dynamic_distiller.py:252-262,461-473) collapse into one, i.e. the image was
-        not rescaled; otherwise the generic path below is taken."""
-        import ctypes
-        from ...hip import lib as _lib
-        from ...hip.runtime import current_stream_ptr
-        from ..losses.cross_entropy_loss import _ce_desc
-        x = self.extract_feat(img)
-        logits = self._decode_head_forward_test(x, img_meta)
-        size = tuple(img.shape[2:])
-        d = _ce_desc(logits, size, None, self.align_corners)
-        seg = torch.empty((img.shape[0],) + size, dtype=torch.int64, device=img.device)
-        L = _lib.load()
-        _lib.check(L.gs_resize_argmax(ctypes.byref(d), logits.data_ptr(), seg.data_ptr(), None,
-                                      current_stream_ptr()), "gs_resize_argmax")
-        return seg
+    def slide_inference(self, img, img_meta, rescale):
+        raise NotImplementedError("slide_inference has no stand-alone form here: the window loop, "
+                                  "normalisation and rescale run inside the fused epilogue "
+                                  "(use inference / simple_test with test_cfg.mode='slide')")
+
+    def whole_inference(self, img, img_meta, rescale):
+        """Logits of the whole image at the input size, rescaled to ori_shape if asked."""
+        logit = self.encode_decode(img, img_meta)
+        if rescale:
+            logit = self._resize_logits(logit, img_meta[0]["ori_shape"][:2])
+        return logit
 
     def simple_test_device(self, img, img_meta, rescale=True):
         """simple_test that keeps the label map on the device: int64 [N, H, W]."""
-        ori = tuple(img_meta[0]["ori_shape"][:2])
-        fused = (self.test_cfg.mode == "whole" and not img_meta[0].get("flip", False)
-                 and (not rescale or ori == tuple(img.shape[2:])))
-        if fused:
-            return self._whole_argmax(img, img_meta, rescale)
-        return self.inference(img, img_meta, rescale).argmax(dim=1)
+        return self._view(img, img_meta, rescale)[0]
 
     def simple_test(self, img, img_meta, rescale=True):
-        ori = tuple(img_meta[0]["ori_shape"][:2])
-        fused = (self.test_cfg.mode == "whole" and not img_meta[0].get("flip", False)
-                 and (not rescale or ori == tuple(img.shape[2:])))
-        if fused:
-            seg_pred = self._whole_argmax(img, img_meta, rescale)
-        else:
-            seg_logit = self.inference(img, img_meta, rescale)
-            seg_pred = seg_logit.argmax(dim=1)
-        return list(seg_pred.cpu().numpy())
+        return list(self.simple_test_device(img, img_meta, rescale).cpu().numpy())
 
     def aug_test(self, imgs, img_metas, rescale=True):
-        assert rescale
-        seg_logit = self.inference(imgs[0], img_metas[0], rescale)
-        for i in range(1, len(imgs)):
-            seg_logit += self.inference(imgs[i], img_metas[i], rescale)
-        seg_logit /= len(imgs)
-        seg_pred = seg_logit.argmax(dim=1)
-        return list(seg_pred.cpu().numpy())
+        """Mean of the per-view probabilities, then argmax (dynamic_distiller.py:523-540): the running
+        sum is carried through the fused kernel; the last view writes only the label map (the
+        division by the number of views does not change the argmax)."""
+        if not rescale:
+            raise ValueError("aug_test needs rescale=True (views of different sizes)")
+        acc = None
+        for k, (img, meta) in enumerate(zip(imgs, img_metas)):
+            last = k == len(imgs) - 1
+            labels, acc = self._view(img, meta, rescale, probs_in=acc, want_probs=not last,
+                                     want_labels=last)
+        return list(labels.cpu().numpy())
 
     def forward_test(self, imgs, img_metas, **kwargs):
-        for var, name in [(imgs, "imgs"), (img_metas, "img_metas")]:
-            if not isinstance(var, list):
-                raise TypeError("%s must be a list, but got %s" % (name, type(var)))
+        if not isinstance(imgs, list) or not isinstance(img_metas, list):
+            raise TypeError("forward_test takes lists (one entry per augmentation), got %s / %s"
+                            % (type(imgs).__name__, type(img_metas).__name__))
         if len(imgs) != len(img_metas):
             raise ValueError("num of augmentations (%d) != num of image meta (%d)"
                              % (len(imgs), len(img_metas)))

@@ -338,6 +338,38 @@ int gs_ohem_weights(const float* prob, int64_t n, int64_t batch_kept, float thre
 int gs_resize_argmax(const gs_ce_desc* d, const float* logits, int64_t* seg, float* probs,
                      void* stream);
 
+/* Whole-image and sliding-window test mode as ONE gather kernel
+ * (dynamic_distiller.py:416-459 slide_inference, :461-473 whole_inference, :475-508 inference,
+ * :510-540 simple_test / aug_test).  The reference accumulates every window's up-sampled logits
+ * into a [N,C,H,W] tensor (159 MB at 1024x2048), counts, divides, resizes to ori_shape, applies
+ * softmax, flips and takes the argmax in separate passes.  Here the low-resolution logits of all
+ * windows stay resident and each output pixel gathers them: nothing of size C*H*W exists unless
+ * the caller asks for the probabilities.
+ *   logits : [ny*nx][N][hl][wl][ld] fp32 (NHWC per window, window index row-major, ld % 4 == 0,
+ *            ld >= C): the decode head's output for every window of hc x wc image pixels
+ *   win_y / win_x : HOST arrays of the ny window-row / nx window-column origins (<= 64 each); the
+ *            window list is their product.  Whole mode: ny = nx = 1, origin 0, hc = H, wc = W.
+ *   pred(y,x) = sum over covering windows of bilinear(logits_win)(y - y0, x - x0) / cover count
+ *   out = resize(pred, (Ho, Wo)) (identity when Ho == H and Wo == W: `rescale` to ori_shape)
+ *   p = softmax_c(out), read at the mirrored position when flip = 1 (horizontal) / 2 (vertical)
+ *   probs_out[N][C][Ho][Wo] = (probs_in ? probs_in : 0) + p     (either may be NULL; may alias)
+ *   labels[N][Ho][Wo]       = argmax_c of that sum (of the logits when no probabilities are used)
+ * Returns GS_E_BADARG if a window leaves the image or a pixel is not covered. */
+typedef struct gs_slide_desc {
+  int32_t N, C, ld;       /* images per window, classes, padded class stride of logits */
+  int32_t hl, wl;         /* low-resolution logits size of one window */
+  int32_t hc, wc;         /* window size in image pixels */
+  int32_t H, W;           /* image size */
+  int32_t Ho, Wo;         /* output size */
+  int32_t ny, nx;         /* window rows / columns */
+  int32_t align_corners;
+  int32_t flip;           /* 0 none, 1 horizontal, 2 vertical */
+  int32_t reserved;       /* must be 0 */
+} gs_slide_desc;
+int gs_slide_fuse(const gs_slide_desc* d, const int32_t* win_y, const int32_t* win_x,
+                  const float* logits, const float* probs_in, float* probs_out, int64_t* labels,
+                  void* stream);
+
 /* mIoU evaluation support: conf[label*C + pred] += 1 over the pixels
  * whose label != ignore_index; conf is [C*C] uint64, accumulated (zero it before the first call).
  * Replaces mmseg's intersect_and_union histogramming behind

@@ -187,7 +187,8 @@ class ODynamicResNet(nn.Module):
             x = self.stem(x)
         else:
             x = O.relu(self.bn1(self.conv1(x)), key=_key(self.bn1))
-        x = self.maxpool(x)
+        mp = self.maxpool   # dynamic_resnet.py:302 MaxPool2d(3, 2, 1)
+        x = O.max_pool2d(x, mp.kernel_size, mp.stride, mp.padding, key="backbone.maxpool")
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

@@ -48,8 +48,10 @@ class ReluMasks:
     RMS, so the test can REQUIRE that disagreements occur only within rounding of zero.
     With masks=None the context only records this side's own masks (self.own)."""
 
-    def __init__(self, masks=None, keep_own=False):
+    def __init__(self, masks=None, keep_own=False, pools=None):
         self.masks = masks
+        self.pools = pools         # key -> uint8 [N, C, Ho, Wo] tap index (kh * k + kw) of the maximum
+        self.pool_flips = {}       # key -> (count, max (own max - chosen value) / rms(x))
         self.keep_own = keep_own
         self.own = {}
         self.pre = {}          # keep_own: the pre-activations themselves
@@ -79,6 +81,26 @@ class ReluMasks:
             self.flips[key] = (n, float(xd[diff].abs().max()) / rms)
         return x * m.to(x.dtype)
 
+    def apply_pool(self, x, key, k, s, p):
+        """max_pool2d with the argmax given: out = x[chosen tap].  Where the given tap is not this
+        side's own maximum the two values must tie within rounding (recorded like ReLU flips)."""
+        idx = self.pools[key].long()
+        n, c, h, w = x.shape
+        ho, wo = idx.shape[2], idx.shape[3]
+        oy = torch.arange(ho).view(1, 1, ho, 1)
+        ox = torch.arange(wo).view(1, 1, 1, wo)
+        iy = oy * s - p + idx // k
+        ix = ox * s - p + idx % k
+        assert bool(((iy >= 0) & (iy < h) & (ix >= 0) & (ix < w)).all()), "pool tap outside the input"
+        out = torch.gather(x.flatten(2), 2, (iy * w + ix).flatten(2)).view(n, c, ho, wo)
+        own = F.max_pool2d(x.detach(), k, s, p)
+        gap = own - out.detach()
+        nflip = int((gap != 0).sum())
+        if nflip:
+            rms = float(x.detach().double().pow(2).mean().sqrt().clamp_min(1e-30))
+            self.pool_flips[key] = (nflip, float(gap.max()) / rms)
+        return out
+
     def __enter__(self):
         global _RELU_CTX
         self._prev = _RELU_CTX
@@ -99,6 +121,13 @@ def relu(x, key=None):
     if _RELU_CTX is None or key is None:
         return torch.relu(x)
     return _RELU_CTX.apply(x, key)
+
+
+def max_pool2d(x, k, s, p, key=None):
+    """F.max_pool2d, or the gather form on externally supplied argmax taps (ReluMasks.pools)."""
+    if _RELU_CTX is None or key is None or _RELU_CTX.pools is None or key not in _RELU_CTX.pools:
+        return F.max_pool2d(x, k, s, p)
+    return _RELU_CTX.apply_pool(x, key, k, s, p)
 
 
 # ---- mmseg.ops.resize == F.interpolate: call sites dynamic_fcn_head.py:141-145 -----------------

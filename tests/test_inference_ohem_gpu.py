@@ -86,3 +86,121 @@ def test_inference_matches_oracle(hip_lib, mode):
     got = torch.from_numpy(np.stack(got))
     mismatch = float((got != want).float().mean())
     assert mismatch < 2e-3, mismatch   # argmax ties / near-ties only
+
+
+# ---- K17: the fused slide / whole epilogue kernel against the oracle's restatement ------------
+class _FakeSegmentor:
+    """encode_decode() hands out pre-drawn low-resolution logits, window after window, up-sampled
+    to the crop like the reference's encode_decode (dynamic_distiller.py:252-262)."""
+
+    class decode_head:
+        align_corners = False
+
+    def __init__(self, low, align):
+        self.low, self.k = low, 0
+        self.decode_head = type("H", (), {"align_corners": align})
+
+    def encode_decode(self, crop):
+        out = F.interpolate(self.low[self.k], size=crop.shape[2:], mode="bilinear",
+                            align_corners=self.decode_head.align_corners)
+        self.k += 1
+        return out
+
+
+@pytest.mark.parametrize("case", [
+    dict(h=96, w=128, crop=(64, 64), stride=(40, 40), low=(8, 8), C=19),
+    dict(h=100, w=100, crop=(33, 47), stride=(17, 29), low=(5, 6), C=19, ori=(75, 131)),
+    dict(h=50, w=70, crop=(64, 64), stride=(32, 32), low=(7, 9), C=19, flip="horizontal"),
+    dict(h=65, w=129, crop=(64, 64), stride=(64, 64), low=(8, 8), C=150, flip="vertical", ori=(97, 200)),
+    dict(h=64, w=96, crop=None, stride=None, low=(8, 12), C=19, align=True, ori=(128, 100)),
+    dict(h=64, w=96, crop=None, stride=None, low=(2, 3), C=37, probs_in=True),
+])
+def test_slide_fuse_kernel_matches_oracle(hip_lib, case):
+    from gaia_seg_amd.core.inference import FusedInference, window_axes
+    from oracle import inference as OI
+    h, w, C = case["h"], case["w"], case["C"]
+    align = case.get("align", False)
+    mode = "slide" if case["crop"] else "whole"
+    if mode == "slide":
+        ys, xs, hc, wc = window_axes(h, w, case["crop"], case["stride"])
+    else:
+        ys, xs, hc, wc = [0], [0], h, w
+    n = 2
+    g = torch.Generator().manual_seed(3)
+    low = torch.randn(len(ys) * len(xs), n, C, *case["low"], generator=g) * 2
+    img = torch.zeros(n, 3, h, w)
+    ori = case.get("ori", (h, w))
+    meta = dict(ori_shape=ori + (3,), flip=bool(case.get("flip")), flip_direction=case.get("flip"))
+    test_cfg = dict(mode=mode)
+    if mode == "slide":
+        test_cfg.update(crop_size=case["crop"], stride=case["stride"])
+    want = OI.inference(_FakeSegmentor(low, align), img, meta, test_cfg, rescale=True)
+    probs_in = None
+    if case.get("probs_in"):
+        probs_in = torch.rand(n, C, *ori, generator=g)
+        want = want + probs_in
+
+    calls = []
+
+    def logits_fn(batch):
+        # windows arrive as one window-major batch: hand back the matching low-resolution maps
+        assert batch.shape[0] == low.shape[0] * n and tuple(batch.shape[2:]) == (hc, wc)
+        calls.append(1)
+        return low.reshape(-1, C, *case["low"]).cuda()
+    eng = FusedInference(C, align)
+    labels, probs = eng(logits_fn, img.cuda(), mode=mode, crop_size=case["crop"], stride=case["stride"],
+                        out_size=ori, flip=case.get("flip"),
+                        probs_in=probs_in.cuda() if probs_in is not None else None, want_probs=True)
+    assert len(calls) == 1
+    assert tuple(probs.shape) == tuple(want.shape)
+    assert float((probs.cpu() - want).abs().max()) < 2e-6
+    differ = labels.cpu() != want.argmax(1)
+    if bool(differ.any()):
+        top2 = want.topk(2, dim=1).values
+        assert float((top2[:, 0] - top2[:, 1])[differ].max()) < 1e-5
+    # labels-only launch (no probabilities in memory) gives the same map
+    labels2, none = eng(logits_fn, img.cuda(), mode=mode, crop_size=case["crop"], stride=case["stride"],
+                        out_size=ori, flip=case.get("flip"))
+    assert none is None
+    if probs_in is None:
+        d2 = labels2.cpu() != want.argmax(1)
+        if bool(d2.any()):
+            top2 = want.topk(2, dim=1).values
+            assert float((top2[:, 0] - top2[:, 1])[d2].max()) < 1e-5
+
+
+def test_slide_fuse_rejects_uncovered_images(hip_lib):
+    import ctypes
+    from gaia_seg_amd.hip import lib
+    L = lib.load()
+    d = lib.SlideDesc()
+    d.N, d.C, d.ld, d.hl, d.wl, d.hc, d.wc = 1, 19, 20, 4, 4, 32, 32
+    d.H, d.W, d.Ho, d.Wo, d.ny, d.nx = 64, 64, 64, 64, 1, 2
+    low = torch.zeros(2, 1, 4, 4, 20, device="cuda")
+    out = torch.zeros(1, 64, 64, dtype=torch.int64, device="cuda")
+    ys, xs = (ctypes.c_int32 * 1)(0), (ctypes.c_int32 * 2)(0, 32)
+    rc = L.gs_slide_fuse(ctypes.byref(d), ys, xs, low.data_ptr(), None, None, out.data_ptr(), None)
+    assert rc == -1      # rows 32..63 are covered by no window: GS_E_BADARG
+
+
+def test_aug_test_averages_view_probabilities(hip_lib):
+    """aug_test over (plain, horizontally flipped) views == argmax of the mean probabilities, the
+    flipped view flipped back (dynamic_distiller.py:523-540)."""
+    from oracle import inference as OI
+    cfg = model_cfg(fcn_head(), aux=True)
+    prod, orc = make_pair(cfg)
+    prod = prod.cuda().eval()
+    orc.eval()
+    meta = arch_meta("sub")
+    prod.manipulate_arch(meta)
+    orc.manipulate_arch(meta)
+    img, _ = make_batch(1, 64, 96)
+    imgs = [img, img.flip(3)]
+    metas = [[dict(ori_shape=(80, 120, 3), flip=False)],
+             [dict(ori_shape=(80, 120, 3), flip=True, flip_direction="horizontal")]]
+    with torch.no_grad():
+        got = prod(img=[i.cuda() for i in imgs], img_metas=metas, return_loss=False)
+        want = OI.aug_test(orc, imgs, [m[0] for m in metas], dict(mode="whole"))
+    got = torch.from_numpy(np.stack(got))
+    assert tuple(got.shape) == (1, 80, 120)
+    assert float((got != want).float().mean()) < 2e-3
