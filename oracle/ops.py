@@ -46,10 +46,19 @@ class ReluMasks:
     around the evaluation point and gradients must agree to rounding.  Every position where the
     given mask differs from this side's own `x > 0` is recorded with |x| relative to the tensor's
     RMS, so the test can REQUIRE that disagreements occur only within rounding of zero.
-    With masks=None the context only records this side's own masks (self.own)."""
+    With masks=None the context only records this side's own masks (self.own).
 
-    def __init__(self, masks=None, keep_own=False, pools=None):
+    `witness`: masks of a second fp32 implementation (this oracle run natively in fp32).  Random
+    deep ReLU networks amplify rounding noise with depth (40+ residual blocks take 6e-8 to ~1e-3 of
+    the activation RMS), so "within rounding of zero" is measured against what the reference's own
+    fp32 arithmetic does at the same layer: witness_flips records the witness's disagreements with
+    this (fp64) side in the same units as flips."""
+
+    def __init__(self, masks=None, keep_own=False, pools=None, witness=None, keep_pre=False):
         self.masks = masks
+        self.witness = witness     # key -> bool mask of ANOTHER fp32 implementation (the fp32 oracle):
+        self.witness_flips = {}    #   its disagreements with this side's signs, recorded like flips
+        self.keep_pre = keep_pre
         self.pools = pools         # key -> uint8 [N, C, Ho, Wo] tap index (kh * k + kw) of the maximum
         self.pool_flips = {}       # key -> (count, max (own max - chosen value) / rms(x))
         self.keep_own = keep_own
@@ -62,7 +71,15 @@ class ReluMasks:
         own = x.detach() > 0
         if self.keep_own:
             self.own[key] = own
+        if self.keep_pre:
             self.pre[key] = x.detach()
+        if self.witness is not None and key in self.witness:
+            wd = own != self.witness[key]
+            nw = int(wd.sum())
+            if nw:
+                xd = x.detach()
+                rms = float(xd.double().pow(2).mean().sqrt().clamp_min(1e-30))
+                self.witness_flips[key] = (nw, float(xd[wd].abs().max()) / rms)
         if self.masks is None:
             return torch.relu(x)
         if key not in self.masks:

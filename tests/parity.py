@@ -8,6 +8,10 @@ ReLU masks and max-pool argmax taps (oracle/ops.py ReluMasks): with equal branch
 evaluate the same smooth function and differ by rounding only.  Where a supplied branch disagrees
 with the oracle's own choice the pre-activation must be within rounding of zero (|x| <= FLIP_TOL *
 rms(x); for a pooling window: the two candidates within FLIP_TOL * rms) — otherwise the test fails.
+"Rounding" is calibrated per layer: a random deep ReLU network amplifies fp32 noise with depth
+(measured on the MI355X box: at block 18 of stage 3 of the MAX subnet the HIP activations are 1.3e-3
+rms from fp64), so the fp32 CPU oracle is run natively once (forward only) as a witness and a flip
+level above FLIP_TOL is accepted only up to COND_FACTOR x the witness's own level at that layer.
 tests/test_grad_criterion.py shows what a single unchecked flip does to a max-norm comparison, which
 is why r01's loose L2 criterion existed and why it is gone.
 
@@ -58,13 +62,27 @@ def hip_train_step(prod, img, gt, metas=None):
     return out, masks, pools
 
 
-def oracle_step(orc, img, gt, masks, pools, dtype=torch.float64):
+def fp32_witness_masks(orc, img, gt):
+    """ReLU masks of the oracle run natively in fp32 (PyTorch-CPU: the reference's arithmetic),
+    forward only; BN buffers are restored afterwards."""
+    from oracle import ops as O
+    orc.float()
+    bufs = {k: v.detach().clone() for k, v in orc.named_buffers()}
+    with torch.no_grad(), O.ReluMasks(None, keep_own=True) as ctx:
+        orc.forward_train(img.float(), gt)
+    with torch.no_grad():
+        for k, b in orc.named_buffers():
+            b.copy_(bufs[k])
+    return ctx.own
+
+
+def oracle_step(orc, img, gt, masks, pools, dtype=torch.float64, witness=None):
     """forward+backward of the oracle on the given branch pattern; returns (losses, loss, ctx)."""
     from oracle import ops as O
     orc.to(dtype)
     for p in orc.parameters():
         p.grad = None
-    with O.ReluMasks(masks, pools=pools) as ctx:
+    with O.ReluMasks(masks, pools=pools, witness=witness) as ctx:
         losses = orc.forward_train(img.to(dtype), gt)
         loss, _ = orc.parse_losses(losses)
         loss.backward()
@@ -74,12 +92,21 @@ def oracle_step(orc, img, gt, masks, pools, dtype=torch.float64):
 
 
 def check_flips(ctx, masks):
-    """Branch disagreements are only allowed within rounding of a tie."""
+    """Branch disagreements are only allowed within rounding of a tie: |x| <= 1e-3 * rms, or — deep
+    in a random network, where fp32 rounding noise itself exceeds that — within COND_FACTOR x the
+    level at which the fp32 CPU oracle disagrees with fp64 at the same layer."""
     total = 0
+    worst = (0.0, None)
     for key, (n, rel) in ctx.flips.items():
-        assert rel <= FLIP_TOL, ("ReLU after %s: %d sign disagreement(s) at |x|/rms = %.2e — not a "
-                                 "rounding-level flip" % (key, n, rel))
+        wit = ctx.witness_flips.get(key, (0, 0.0))[1]
+        assert rel <= max(FLIP_TOL, COND_FACTOR * wit), (
+            "ReLU after %s: %d sign disagreement(s) at |x|/rms = %.2e (fp32 oracle: %.2e) — not a "
+            "rounding-level flip" % (key, n, rel, wit))
+        if rel > worst[0]:
+            worst = (rel, key, wit)
         total += n
+    if VERBOSE and worst[1] is not None:
+        print("[parity] largest flip level %.2e at %s (fp32 oracle there: %.2e)" % worst)
     for key, (n, rel) in ctx.pool_flips.items():
         assert rel <= FLIP_TOL, ("%s: %d argmax disagreement(s), candidates %.2e * rms apart — not a "
                                  "tie" % (key, n, rel))
@@ -153,8 +180,10 @@ def compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=True, check_b
 def train_step_parity(prod, orc, img, gt, check_grads=True):
     """The whole protocol; prod is on cuda / train mode with its arch set, orc likewise (CPU)."""
     out, masks, pools = hip_train_step(prod, img, gt)
+    witness = fp32_witness_masks(orc, img, gt)
     bufs0 = {k: v.detach().clone() for k, v in orc.named_buffers()}
-    losses_o, loss_o, ctx = oracle_step(orc, img, gt, masks, pools)
+    losses_o, loss_o, ctx = oracle_step(orc, img, gt, masks, pools, witness=witness)
+    del witness
     nflips = check_flips(ctx, masks)
 
     def fp32_grads():

@@ -17,7 +17,8 @@ import os
 import pytest
 import torch
 
-from parity import check_flips, compare_step, hip_train_step, oracle_step, train_step_parity
+from parity import (check_flips, compare_step, fp32_witness_masks, hip_train_step, oracle_step,
+                    train_step_parity)
 from util_models import make_pair
 
 pytestmark = pytest.mark.gpu
@@ -178,7 +179,8 @@ def test_config5_ohem_train_loss_2048x1024(hip_lib):
     img, gt = _batch(1, 1024, 2048)
     try:
         out, masks, pools = hip_train_step(prod, img, gt)
-        losses_o, loss_o, ctx = oracle_step(orc, img, gt, masks, pools)
+        witness = fp32_witness_masks(orc, img, gt)
+        losses_o, loss_o, ctx = oracle_step(orc, img, gt, masks, pools, witness=witness)
         check_flips(ctx, masks)
     except BaseException:
         orc.decode_head.sampler = None

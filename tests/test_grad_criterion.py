@@ -19,7 +19,7 @@ from util_models import arch_meta, fcn_head, make_batch, make_pair, model_cfg
 def _grads(orc, img, gt, masks=None, keep=False):
     for p in orc.parameters():
         p.grad = None
-    with O.ReluMasks(masks, keep_own=keep) as ctx:
+    with O.ReluMasks(masks, keep_own=keep, keep_pre=keep) as ctx:
         loss, _ = orc.parse_losses(orc.forward_train(img, gt))
         loss.backward()
     return float(loss), {n: p.grad.clone() for n, p in orc.named_parameters() if p.grad is not None}, ctx
