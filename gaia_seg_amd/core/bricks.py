@@ -335,8 +335,9 @@ def build_activation_layer(cfg):
     return build_from_cfg(cfg, ACTIVATION_LAYERS)
 
 
-def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=None):
-    """conv -> norm (+ residual) (+ ReLU).  Rank-local BatchNorm after a bias-free conv goes through
+def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=None, defer=False):
+    """conv -> norm (+ residual) (+ ReLU).  ``defer``: leave the BN + ReLU to the consumer's operand
+    loaders where the fused path allows it (ops.conv_bn).  Rank-local BatchNorm after a bias-free conv goes through
     the one-call-per-direction library entry (ops.conv_bn); SyncBN with a process group, a conv
     bias, widths that are not multiples of 4 and subnet extraction take the module-by-module path.
     Both paths launch the same kernels."""
@@ -348,7 +349,8 @@ def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=No
         if bnp.process_group is None:
             conv._check_layout()
             return ops.conv_bn(tape, x, conv.weight, c, bnp, conv.stride, conv.padding,
-                               conv.dilation, relu=relu, residual=residual, out=out, tag=tag)
+                               conv.dilation, relu=relu, residual=residual, out=out, tag=tag,
+                               defer=defer)
     y = conv.forward_act(tape, x, tag=tag)
     return norm.forward_act(tape, y, relu=relu, residual=residual, out=out)
 
@@ -498,8 +500,10 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
                     else:
                         raise NotImplementedError("downsample member %s (avg_down) has no HIP "
                                                   "kernel yet" % type(m).__name__)
-        out = conv_bn_act(tape, self.conv1, self.norm1, x, relu=True)
-        out = conv_bn_act(tape, self.conv2, self.norm2, out, relu=True, tag="k3")
+        # bn1 -> conv2 and bn2 -> conv3: the normalised activations are never stored; conv2 / conv3
+        # (forward and weight gradient) evaluate relu(bn(.)) in their operand loaders
+        out = conv_bn_act(tape, self.conv1, self.norm1, x, relu=True, defer=True)
+        out = conv_bn_act(tape, self.conv2, self.norm2, out, relu=True, tag="k3", defer=True)  # K3
         return conv_bn_act(tape, self.conv3, self.norm3, out, relu=True, residual=identity)
 
     def forward(self, x):

@@ -36,7 +36,7 @@ extern "C" int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const f
                                   const gs_bn_args* bn, const float* residual, int32_t ld_res,
                                   float* y, float* coeffs, float* z, int32_t ldz, void* workspace,
                                   size_t workspace_bytes, void* stream) {
-  if (!d || !bn || !coeffs || !z) return GS_E_NULL;
+  if (!d || !bn || !coeffs) return GS_E_NULL;
   static const bool no_fuse = getenv("GS_NO_STATS_FUSION") != nullptr;
   ConvFwdInfo info{};
   int rc = conv2d_forward_impl(d, x, w, nullptr, nullptr, y, workspace, workspace_bytes, stream,
@@ -69,6 +69,8 @@ extern "C" int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const f
                            coeffs, stream);
   }
   if (rc != GS_OK) return rc;
+  // z == NULL: the consumer applies relu(bn(y)) in its operand loader (gs_conv_desc::in_affine)
+  if (!z) return residual ? GS_E_BADARG : GS_OK;
   return gs_bn_apply(y, rows, C, d->ldy, coeffs, residual, ld_res, bn->relu, z, ldz, stream);
 }
 

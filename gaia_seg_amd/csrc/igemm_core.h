@@ -64,7 +64,22 @@ struct IgemmArgs {
   // forward only: per-tile BatchNorm partial sums written by the epilogue (NULL = off), quad-major
   // {s1, s2, shift}[C/4][tiles_m] float4 with shift = the tile's first row (see rows_epilogue)
   float* tile_stats;
+  // fast forward / wgrad kernels: when set, the gathered operand is relu(bn(src)) evaluated on the
+  // fly from the producer BatchNorm's coefficients [scale | beta | mean | invstd][Cs] (the
+  // normalised activation is never stored; padding stays exactly zero)
+  const float* a_coeffs;
 };
+
+constexpr int kAffMaxC = 640;   // widest gathered operand of the supernet (stage-4 planes)
+
+// relu((v - mean) * scale + beta): the expression of bn_apply_kernel / masked_grad (norm.hip), so
+// that the forward value, the backward mask and the fused loaders agree bit for bit
+__device__ __forceinline__ f32x4 bn_relu_affine(f32x4 v, f32x4 mean, f32x4 scale, f32x4 beta) {
+  v = (v - mean) * scale + beta;
+  v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+  v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+  return v;
+}
 
 // pixel index of GEMM row m in the output tensor
 __device__ __forceinline__ long out_pixel(const IgemmArgs& p, int m) {
@@ -620,12 +635,20 @@ __device__ __forceinline__ unsigned long long gs_stamp() {
 }
 // ROLE only names the instantiation (gs_conv_desc::role): role 1 = the bottleneck conv2 (K3), so
 // that rocprofv3 attributes the headline kernel separately from the other 3x3 convolutions.
+// AFF: the gathered operand is relu(bn(src)) (IgemmArgs::a_coeffs): the producer BatchNorm's
+// coefficients sit in LDS behind the tile stages; each register set of the pipelined loop carries,
+// besides its AS data quads, the three coefficient quads of its K step (fetched from LDS when the
+// global loads are issued, two K steps before they are needed) and the tap-validity bits, so the
+// affine + ReLU + zero-padding select run in the store slot on values that are already there.
 template <int BM, int BN, bool BTRANS, int KS, int ABL = 0, int ROLE = 0, bool PIPE = true,
-          bool PAIR = false>
+          bool PAIR = false, bool AFF = false>
 __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
-  __shared__ __attribute__((aligned(16))) float lds[PAIR ? T::LDSF2 : T::LDSF];
+  constexpr int LDS_TILES = PAIR ? T::LDSF2 : T::LDSF;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_TILES + (AFF ? 3 * kAffMaxC : 0)];
   constexpr int AS = BM / 64;
+  constexpr int AX = AFF ? AS + 4 : AS;   // register-set size handed to the pipelined loop
+  static_assert(!AFF || (PIPE && !BTRANS && ABL == 0), "AFF: forward, pipelined loop only");
   constexpr int MAXTAPS = KS * KS;  // KS only bounds the tap loop and tags the kernel name
   const int ntaps = p.kh_n * p.kw_n;
 
@@ -702,6 +725,19 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
   // block-uniform position of the next K step to load
   int tap = (kt0 * BK) / p.Cs;
   int c0 = kt0 * BK - tap * p.Cs;
+
+  float* coefL = lds + LDS_TILES;   // AFF: [mean | scale | beta][Cs]
+  if constexpr (AFF) {
+    const int cq = p.Cs >> 2;
+    for (int i = t; i < 3 * cq; i += NT) {
+      const int which = i / cq, q = i - which * cq;
+      // coefficient order in memory: scale, beta, mean, invstd
+      const int srcrow = which == 0 ? 2 : (which == 1 ? 0 : 1);
+      *reinterpret_cast<f32x4*>(coefL + which * p.Cs + q * 4) =
+          *reinterpret_cast<const f32x4*>(p.a_coeffs + (long)srcrow * p.Cs + q * 4);
+    }
+    __syncthreads();
+  }
 
   f32x4 acc[T::TM][T::TN];
 #pragma unroll
@@ -784,15 +820,24 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     int bbase = kh * b_step_h + kw * b_step_w + c0 * b_cmul;
     unsigned tapbit = tap < 32 ? (1u << tap) : 0u;
     int k_left = nk;
-    auto load_a = [&](f32x4 (&ra)[AS]) __attribute__((always_inline)) {
+    auto load_a = [&](f32x4 (&ra)[AX]) __attribute__((always_inline)) {
       const bool kvalid = k_left > 0;
+      unsigned okbits = 0;
 #pragma unroll
       for (int s = 0; s < AS; ++s) {
         const bool ok = kvalid && (vmask[s] & tapbit) != 0;
         const unsigned off = ok ? (unsigned)(rowoff[s] + aoff) : kOOB;
+        okbits |= (ok ? 1u : 0u) << s;
         if constexpr (ABL >= 1 && ABL != 9) ra[s] = f32x4{(float)off, 1.f, 2.f, 3.f};
         else
           ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
+      }
+      if constexpr (AFF) {
+        const float* cp = coefL + c0 + kq * 4;   // channels of this K step handled by this thread
+        ra[AS] = *reinterpret_cast<const f32x4*>(cp);
+        ra[AS + 1] = *reinterpret_cast<const f32x4*>(cp + p.Cs);
+        ra[AS + 2] = *reinterpret_cast<const f32x4*>(cp + 2 * p.Cs);
+        ra[AS + 3][0] = __builtin_bit_cast(float, okbits);
       }
     };
     auto load_b = [&](f32x4 (&rb)[T::BV]) __attribute__((always_inline)) {
@@ -819,13 +864,19 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
       aoff = kh * a_step_h + kw * a_step_w + 4 * c0;
       bbase = kh * b_step_h + kw * b_step_w + c0 * b_cmul;
     };
-    auto store_a = [&](const f32x4 (&ra)[AS], float* As) __attribute__((always_inline)) {
+    auto store_a = [&](const f32x4 (&ra)[AX], float* As) __attribute__((always_inline)) {
       if constexpr (ABL >= 2 && ABL != 9) { asm volatile("" ::"v"(ra[0][0])); return; }
 #pragma unroll
       for (int s = 0; s < AS; ++s) {
         const int row = (t >> 2) + 64 * s;
+        f32x4 v = ra[s];
+        if constexpr (AFF) {
+          const unsigned okbits = __builtin_bit_cast(unsigned, ra[AS + 3][0]);
+          v = bn_relu_affine(v, ra[AS], ra[AS + 1], ra[AS + 2]);
+          if (!((okbits >> s) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding of the ACTIVATION
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * T::PA + 8 * kq + row] = ra[s][j];
+        for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * T::PA + 8 * kq + row] = v[j];
       }
     };
     auto store_b = [&](const f32x4 (&rb)[T::BV], float* Bs) __attribute__((always_inline)) {
@@ -847,9 +898,9 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     };
     GS_STAMP(st_l0)
     if constexpr (PAIR)
-      pipelined_k_loop_pairs<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
+      pipelined_k_loop_pairs<BM, BN, AX>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
     else
-      pipelined_k_loop<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
+      pipelined_k_loop<BM, BN, AX>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
   } else {
   // step i computes from buf[i&1]; two register sets hold steps i+1 and i+2 (in flight); the set
   // freed at step i is refilled with step i+3.  Unrolled by 6: buffer parity and set index static.
@@ -1058,12 +1109,16 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_kernel(const IgemmArgs p) {
 // WALIGN: Wp % BK == 0, so the BK pixels of a K step lie in one image row: (n, h, w0) of the step are
 // scalars and the per-thread gather state (three counters with carries, ~20 VALU per K step inside
 // the MFMA stream) reduces to two adds.
-template <int BM, int BN, int KS, bool PAIR = false, bool WALIGN = false>
+// AFF: the gathered operand is relu(bn(src)) (IgemmArgs::a_coeffs).  A thread's four GEMM rows are
+// four fixed channels, so their coefficients live in registers for the whole kernel; each register
+// set carries one extra quad with the validity bits of its loads (padding must stay zero).
+template <int BM, int BN, int KS, bool PAIR = false, bool WALIGN = false, bool AFF = false>
 __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
   __shared__ __attribute__((aligned(16))) float lds[PAIR ? T::LDSF2 : T::LDSF];
   constexpr int QA = BM / 4;
   constexpr int AS = BK * QA / NT;  // 1 (BM = 64) or 2 (BM = 128)
+  constexpr int AX = AFF ? AS + 1 : AS;
   constexpr int KSTR = NT / QA;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1094,6 +1149,12 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
   const int kwid = KS ? KS : p.KW;
   const int kh = tap / kwid, kw = tap - kh * kwid;
   const int offh = p.base_h + kh * p.step_h, offw = p.base_w + kw * p.step_w;
+  f32x4 a_mean{0.f, 0.f, 0.f, 0.f}, a_scale{0.f, 0.f, 0.f, 0.f}, a_beta{0.f, 0.f, 0.f, 0.f};
+  if constexpr (AFF) {   // coefficient order in memory: scale, beta, mean, invstd
+    a_scale = *reinterpret_cast<const f32x4*>(p.a_coeffs + c);
+    a_beta = *reinterpret_cast<const f32x4*>(p.a_coeffs + p.Cs + c);
+    a_mean = *reinterpret_cast<const f32x4*>(p.a_coeffs + 2 * p.Cs + c);
+  }
   // pixel state per slot, advanced by BK pixels per K step
   int pn[AS], ph[AS], pw[AS];
   const int hw = p.Hp * p.Wp;
@@ -1139,8 +1200,9 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
     s_w0 = rem - s_h * p.Wp;
   }
   const int cw_off = krA * p.mul_w + offw;   // + s * KSTR * mul_w per slot
-  auto load_a = [&](f32x4 (&ra)[AS]) __attribute__((always_inline)) {
+  auto load_a = [&](f32x4 (&ra)[AX]) __attribute__((always_inline)) {
     const bool kvalid = k_left > 0;
+    unsigned okbits = 0;
     if constexpr (WALIGN) {
       const bool rowv = kvalid && s_n < Nb;
       const int hb = s_h * p.mul_h, wb = s_w0 * p.mul_w;
@@ -1152,8 +1214,10 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
         const bool ok = rowv && iv && (unsigned)hi < (unsigned)p.Hs && (unsigned)wi < (unsigned)p.Ws;
         const unsigned off =
             ok ? 4u * (unsigned)(nbase + hi * (int)p.s_h + wi * (int)p.s_w + c) : kOOB;
+        okbits |= (ok ? 1u : 0u) << s;
         ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
       }
+      if constexpr (AFF) ra[AS][0] = __builtin_bit_cast(float, okbits);
       const int w2 = s_w0 + BK;
       const int cw = w2 >= p.Wp ? 1 : 0;
       s_w0 = w2 * (1 - cw);
@@ -1170,6 +1234,7 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
                       (unsigned)wi < (unsigned)p.Ws;
       const unsigned off =
           ok ? 4u * (unsigned)(pn[s] * (int)p.s_n + hi * (int)p.s_h + wi * (int)p.s_w + c) : kOOB;
+      okbits |= (ok ? 1u : 0u) << s;
       ra[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
       const int w2 = pw[s] + adv_w;
       const int cw = w2 >= p.Wp ? 1 : 0;
@@ -1179,6 +1244,7 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
       ph[s] = h2 - (ch ? p.Hp : 0);
       pn[s] += adv_n + ch;
     }
+    if constexpr (AFF) ra[AS][0] = __builtin_bit_cast(float, okbits);
   };
   auto load_b = [&](f32x4 (&rb)[T::BV]) __attribute__((always_inline)) {
     const bool kvalid = k_left > 0;
@@ -1192,11 +1258,17 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
     ++kt_load;
     --k_left;
   };
-  auto store_a = [&](const f32x4 (&ra)[AS], float* As) __attribute__((always_inline)) {
+  auto store_a = [&](const f32x4 (&ra)[AX], float* As) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < AS; ++s) {
       const int kr = krA + s * KSTR;
-      *reinterpret_cast<f32x4*>(&As[kr * T::PA + 8 * (kr >> 2) + iq * 4]) = ra[s];
+      f32x4 v = ra[s];
+      if constexpr (AFF) {
+        const unsigned okbits = __builtin_bit_cast(unsigned, ra[AS][0]);
+        v = bn_relu_affine(v, a_mean, a_scale, a_beta);
+        if (!((okbits >> s) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      *reinterpret_cast<f32x4*>(&As[kr * T::PA + 8 * (kr >> 2) + iq * 4]) = v;
     }
   };
   auto store_b = [&](const f32x4 (&rb)[T::BV], float* Bs) __attribute__((always_inline)) {
@@ -1210,9 +1282,9 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
     }
   };
   if constexpr (PAIR)
-    pipelined_k_loop_pairs<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
+    pipelined_k_loop_pairs<BM, BN, AX>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
   else
-    pipelined_k_loop<BM, BN, AS>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
+    pipelined_k_loop<BM, BN, AX>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
 
   float* Cs = lds;
   constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
@@ -1449,6 +1521,21 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
   // their fill / drain (r01 A/B: s2..s4 3x3 and the head convs +3..7 %, s1 3x3 -3 % if paired)
   const bool pair = pl.nk_per_split >= pair_min_ksteps() &&
                     (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
+  if constexpr (!BTRANS) {
+    if (a.a_coeffs) {   // relu(bn(x)) evaluated in the loader: 64-row tiles (the planner's choice)
+#define GS_FAST_AFF(BN_)                                                                   \
+  if (pl.bm == 64 && pl.bn == BN_) {                                                       \
+    if (pair)                                                                              \
+      hipLaunchKernelGGL((igemm_rows_fast_kernel<64, BN_, false, KS, 0, ROLE, true, true, true>), grid, block, 0, st, a); \
+    else                                                                                   \
+      hipLaunchKernelGGL((igemm_rows_fast_kernel<64, BN_, false, KS, 0, ROLE, true, false, true>), grid, block, 0, st, a); \
+    return;                                                                                \
+  }
+      GS_FAST_AFF(128) GS_FAST_AFF(96) GS_FAST_AFF(80) GS_FAST_AFF(64) GS_FAST_AFF(48) GS_FAST_AFF(32)
+#undef GS_FAST_AFF
+      return;   // (unreachable: conv_in_affine_ok() admits only plans with 64-row tiles)
+    }
+  }
 #define GS_FAST(BM_, BN_)                                                                  \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                      \
     if (pair)                                                                              \
@@ -1477,6 +1564,23 @@ static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t
                     (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
   static const int no_walign = env_int("GS_NO_WALIGN", 0);
   const bool walign = !no_walign && a.Wp % BK == 0;
+  if (a.a_coeffs) {
+#define GS_WGF_AFF(BN_)                                                                   \
+  if (pl.bm == 64 && pl.bn == BN_) {                                                      \
+    if (pair && walign)                                                                   \
+      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<64, BN_, KS, true, true, true>), grid, block, 0, st, a); \
+    else if (pair)                                                                        \
+      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<64, BN_, KS, true, false, true>), grid, block, 0, st, a); \
+    else if (walign)                                                                      \
+      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<64, BN_, KS, false, true, true>), grid, block, 0, st, a); \
+    else                                                                                  \
+      hipLaunchKernelGGL((igemm_wgrad_fast_kernel<64, BN_, KS, false, false, true>), grid, block, 0, st, a); \
+    return;                                                                               \
+  }
+    GS_WGF_AFF(128) GS_WGF_AFF(96) GS_WGF_AFF(80) GS_WGF_AFF(64) GS_WGF_AFF(48) GS_WGF_AFF(32)
+#undef GS_WGF_AFF
+    return;
+  }
 #define GS_WGF(BM_, BN_)                                                                  \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                     \
     if (pair && walign)                                                                   \
@@ -1589,6 +1693,19 @@ static inline TapAxis tap_axis(int ph, int pad, int dil, int s, int K) {
   return a;
 }
 static inline int class_len(int L, int s, int ph) { return L > ph ? (L - ph + s - 1) / s : 0; }
+
+// gs_conv_desc::in_affine (relu(bn(x)) in the operand loaders) needs the fast forward and wgrad
+// kernels with 64-row tiles and the coefficient image in LDS
+static inline bool conv_in_affine_ok(const gs_conv_desc* d) {
+  if (!x_is_vector(d) || d->Ci > kAffMaxC || (d->Ci % BK) != 0) return false;
+  const int ks = (d->KH == 1 && d->KW == 1) ? 1 : ((d->KH == 3 && d->KW == 3) ? 3 : 0);
+  if (!ks) return false;
+  const size_t src_b = (size_t)d->N * d->x_sn * sizeof(float);
+  const size_t dense_b = (size_t)d->KH * d->KW * d->Ci_max * d->Co_ld * sizeof(float);
+  if (!fast_rows_ok(d->Ci, ks, src_b, dense_b) || getenv("GS_NO_FAST")) return false;
+  if ((d->Ci & 3) || (d->Co & 3)) return false;
+  return plan_fwd(d).bm == 64 && plan_wgrad(d).bm == 64;
+}
 
 static inline int ksize_tag(const gs_conv_desc* d) {
   if (d->KH == 1 && d->KW == 1) return 1;

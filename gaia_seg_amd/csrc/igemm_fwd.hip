@@ -70,6 +70,11 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
   a.src_bytes = (unsigned)src_b;
   a.dense_bytes = (unsigned)dense_b;
   const bool fast = vec && fast_rows_ok(d->Ci, ks, src_b, dense_b) && getenv("GS_NO_FAST") == nullptr;
+  if (d->in_affine) {
+    if (!conv_in_affine_ok(d) || !fast || pl.bm != 64) return GS_E_BADARG;
+    if (!aligned16(d->in_affine)) return GS_E_ALIGN;
+    a.a_coeffs = d->in_affine;
+  }
   const bool timed = d->role == GS_CONV_ROLE_BOTTLENECK3X3 && k3_prof_on();
   if (timed) k3_prof_begin(st);
   const double flops = 2.0 * (double)M * d->Co * d->Ci * d->KH * d->KW;
@@ -109,6 +114,11 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
   return rc;
 }
 }  // namespace gs
+
+extern "C" int gs_conv2d_in_affine_supported(const gs_conv_desc* d) {
+  if (check_desc(d) != GS_OK) return 0;
+  return conv_in_affine_ok(d) ? 1 : 0;
+}
 
 extern "C" int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const float* w,
                                  const float* bias, const float* addend, float* y, void* workspace,

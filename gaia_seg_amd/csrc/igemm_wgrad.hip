@@ -37,6 +37,11 @@ extern "C" int gs_conv2d_wgrad(const gs_conv_desc* d, const float* x, const floa
   a.dense_bytes = (unsigned)dense_b;
   const bool fast = vec && src_b < (1ull << 31) && dense_b < (1ull << 31) &&
                     getenv("GS_NO_FAST") == nullptr;
+  if (d->in_affine) {
+    if (!conv_in_affine_ok(d) || !fast || pl.bm != 64 || (ks != 1 && ks != 3)) return GS_E_BADARG;
+    if (!aligned16(d->in_affine)) return GS_E_ALIGN;
+    a.a_coeffs = d->in_affine;
+  }
   if (fast && ks == 1) launch_wgrad_fast<1>(pl, a, st);
   else if (fast && ks == 3) launch_wgrad_fast<3>(pl, a, st);
   else if (fast) launch_wgrad_fast<0>(pl, a, st);

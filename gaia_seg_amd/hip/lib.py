@@ -16,7 +16,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgaiaseg_hip.so")
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HipLibraryError(RuntimeError):
@@ -30,7 +30,7 @@ class ConvDesc(Structure):
                 ("stride", c_int32), ("pad", c_int32), ("dil", c_int32), ("Ho", c_int32),
                 ("Wo", c_int32), ("x_sn", c_int64), ("x_sh", c_int64), ("x_sw", c_int64),
                 ("x_sc", c_int64), ("ldy", c_int32), ("ld_add", c_int32),
-                ("role", c_int32), ("reserved", c_int32)]
+                ("role", c_int32), ("reserved", c_int32), ("in_affine", c_void_p)]
 
 
 class BnArgs(Structure):
@@ -64,6 +64,7 @@ PROTOTYPES = {
     "gs_error_string": (c_char_p, [_i32]),
     "gs_target_arch": (c_char_p, []),
     "gs_conv2d_workspace_bytes": (_sz, [_CD]),
+    "gs_conv2d_in_affine_supported": (_i32, [_CD]),
     "gs_conv2d_forward": (_i32, [_CD, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "gs_conv2d_dgrad": (_i32, [_CD, _P, _P, _P, _i32, _P, _sz, _P]),
     "gs_conv2d_wgrad": (_i32, [_CD, _P, _P, _P, _P, _sz, _P]),

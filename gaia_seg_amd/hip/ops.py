@@ -152,11 +152,37 @@ def _trace_relu(bn, out):
         RELU_TRACE.append((bn.weight, out.t > 0))
 
 
+def _trace_relu_deferred(bn, y, coeffs):
+    """Same for a deferred BN+ReLU: the mask comes from the real apply kernel (same expression as the
+    fused loaders and the backward mask), run into a scratch buffer only while tracing."""
+    if RELU_TRACE is not None and bn.weight is not None:
+        tmp = Act.empty(y.N, y.H, y.W, y.C, y.t.device)
+        _lib.check(_L().gs_bn_apply(y.ptr, y.rows, y.C, y.ld, coeffs.data_ptr(), None, 0, 1, tmp.ptr,
+                                    tmp.ld, current_stream_ptr()), "gs_bn_apply")
+        RELU_TRACE.append((bn.weight, tmp.t > 0))
+
+
+DEFER_BN = os.environ.get("GS_NO_DEFER_BN") is None   # bn1 -> conv2 / bn2 -> conv3 loader fusion
+
+
+def materialize(tape, x):
+    """Write out relu(bn(t)) of a deferred activation (consumers without the loader fusion)."""
+    if x.affine is None:
+        return x
+    z = Act.empty(x.N, x.H, x.W, x.C, x.t.device)
+    _lib.check(_L().gs_bn_apply(x.ptr, x.rows, x.C, x.ld, x.affine.data_ptr(), None, 0, 1, z.ptr, z.ld,
+                                current_stream_ptr()), "gs_bn_apply")
+    z.requires_grad = x.requires_grad
+    add_grad_passthrough(tape, x, z)
+    return z
+
+
 def conv2d(tape, x, weight, bias, co, stride=1, pad=0, dil=1, out=None, tag=None):
     """DynConv2d forward: y = conv(x, weight[:co, :x.C]) (+ bias[:co]).
 
     ``co`` is the active output width; the active input width is x.C."""
     L = _L()
+    x = materialize(tape, x)
     co_eff = round_up(co, 4)
     dev = x.t.device
     kh, kw = weight.shape[2], weight.shape[3]
@@ -303,6 +329,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
     running statistics updated on the slice; eval: running statistics.  ``inplace`` reuses x's
     storage for y (only when x is not needed by backward, i.e. never in training)."""
     L = _L()
+    x = materialize(tape, x)
     dev = x.t.device
     C, rows = x.C, x.rows
     st = current_stream_ptr()
@@ -413,11 +440,16 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
 
 
 def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
-            tag=None):
+            tag=None, defer=False):
     """z = act(BN(conv(x, weight[:co, :x.C])) (+ residual)) through ONE library call per direction
     (gs_conv_bn_forward / gs_conv_bn_backward): same kernels, same results as conv2d() followed by
     batchnorm(), a third of the host work.  Rank-local BatchNorm only (``bn.process_group`` None);
-    the conv has no bias."""
+    the conv has no bias.
+
+    ``defer`` (with relu, no residual, no ``out``): the BN + ReLU is NOT applied here; the returned
+    activation carries the coefficients (Act.affine) and its consumer — the next conv_bn — evaluates
+    relu(bn(y)) in its operand loaders, forward and weight gradient (gs_conv_desc.in_affine).  A
+    deferred INPUT ``x`` is consumed that way when the library supports the shape, else written out."""
     L = _L()
     co_eff = round_up(co, 4)
     dev = x.t.device
@@ -426,6 +458,7 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
         n, _, h, w = x.t.shape
     else:
         n, h, w = x.N, x.H, x.W
+    defer = bool(defer and DEFER_BN and relu and residual is None and out is None)
     ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(w, kw, stride, pad, dil)
     rows = n * ho * wo
     use_batch = bn.training or bn.running_mean is None
@@ -433,9 +466,18 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
         raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                          % ((n, co, ho, wo),))
     y = Act.empty(n, ho, wo, co, dev)
-    if out is None:
-        out = Act.empty(n, ho, wo, co, dev)
+    if x.affine is not None:
+        d = _conv_desc(x, weight, co_eff, stride, pad, dil, y.ld, role=1 if tag == "k3" else 0)
+        if not L.gs_conv2d_in_affine_supported(ctypes.byref(d)):
+            x = materialize(tape, x)
     d = _conv_desc(x, weight, co_eff, stride, pad, dil, y.ld, role=1 if tag == "k3" else 0)
+    in_affine = x.affine   # kept alive by the backward closure
+    if in_affine is not None:
+        d.in_affine = in_affine.data_ptr()
+    if defer:
+        out = y
+    elif out is None:
+        out = Act.empty(n, ho, wo, co, dev)
     C = co_eff
     if y.C != C:   # channel counts that are not multiples of 4 keep the two-step path
         raise ValueError("conv_bn needs an output width that is a multiple of 4, got %d" % co)
@@ -455,11 +497,15 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
     _lib.check(L.gs_conv_bn_forward(ctypes.byref(d), x.ptr, weight.data_ptr(), ctypes.byref(args),
                                     residual.ptr if residual is not None else None,
                                     residual.ld if residual is not None else 0, y.ptr,
-                                    coeffs.data_ptr(), out.ptr, out.ld, ws.data_ptr(), ws.numel(),
-                                    current_stream_ptr()), "gs_conv_bn_forward")
+                                    coeffs.data_ptr(), None if defer else out.ptr, out.ld,
+                                    ws.data_ptr(), ws.numel(), current_stream_ptr()),
+               "gs_conv_bn_forward")
     if use_batch and bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked()
-    if relu:
+    if defer:
+        out.affine = coeffs
+        _trace_relu_deferred(bn, y, coeffs)
+    elif relu:
         _trace_relu(bn, out)
 
     def backward():

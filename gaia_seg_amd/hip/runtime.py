@@ -74,7 +74,7 @@ class Act:
     ``nchw_image`` marks the network input, which is read in place through NCHW strides."""
 
     __slots__ = ("t", "_g", "requires_grad", "parent", "c0", "nchw_image",
-                 "N", "H", "W", "C", "ld", "rows", "ptr")
+                 "N", "H", "W", "C", "ld", "rows", "ptr", "affine")
 
     def __init__(self, t, requires_grad=True, parent=None, c0=0, nchw_image=False):
         self.t = t
@@ -83,6 +83,11 @@ class Act:
         self.parent = parent
         self.c0 = c0
         self.nchw_image = nchw_image
+        # Deferred BatchNorm + ReLU: when set (a coefficient tensor [scale | beta | mean | invstd][C]),
+        # the LOGICAL value of this activation is relu(bn(t)) and ``t`` holds the BN input; the
+        # consumer convolution applies it in its operand loader (gs_conv_desc.in_affine) or
+        # ops.materialize() writes it out.  ``g`` is always the gradient of the logical value.
+        self.affine = None
         # geometry, fixed for the life of the object (t is never rebound): plain attributes, these
         # are read several times per kernel launch
         shp = t.shape

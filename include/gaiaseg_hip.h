@@ -64,7 +64,18 @@ typedef struct gs_conv_desc {
   int32_t ld_add;         /* pixel stride of the optional addend (0 if unused)               */
   int32_t role;           /* GS_CONV_ROLE_*: profiling label only, results are identical     */
   int32_t reserved;       /* must be 0                                                       */
+  /* Optional: x is the INPUT of a BatchNorm + ReLU whose output the convolution consumes
+   * (bottleneck bn1 -> conv2, bn2 -> conv3).  in_affine = that BatchNorm's coefficient block
+   * [scale | beta | mean | invstd][Ci] (as written by gs_conv_bn_forward / gs_bn_finalize) and the
+   * forward and weight-gradient kernels evaluate relu((x - mean) * scale + beta) in their operand
+   * loaders: the normalised activation is never written to or read from HBM, zero padding applies
+   * to the activation.  gs_conv2d_dgrad ignores it (its result is the gradient w.r.t. the
+   * activation).  Only where gs_conv2d_in_affine_supported(d) != 0; NULL = x is used as it is. */
+  const float* in_affine;
 } gs_conv_desc;
+/* 1 if gs_conv2d_forward / gs_conv2d_wgrad / gs_conv_bn_* accept d->in_affine for this shape
+ * (NHWC x, 1x1 or 3x3, Ci % 16 == 0, Ci <= 640: the fast kernels with 64-row tiles). */
+int gs_conv2d_in_affine_supported(const gs_conv_desc* d);
 /* role = GS_CONV_ROLE_BOTTLENECK3X3 marks conv2 of DynamicBottleneck (SURVEY.md K3,
  * gaiaseg/models/utils/dynamic_res_layer.py:96-106): the forward dispatches an identically compiled
  * but separately NAMED kernel instantiation (igemm_rows_fast_kernel<..., 1> and
@@ -191,7 +202,10 @@ typedef struct gs_bn_args {
 /* max(gs_conv2d_workspace_bytes, gs_bn_stats_workspace_bytes) for this conv's output */
 size_t gs_conv_bn_workspace_bytes(const gs_conv_desc* d);
 /* y = conv(x, w) [N*Ho*Wo][ldy] (kept for backward); coeffs[4*Co] (kept for backward);
- * z = relu?(BN(y) (+ residual)) with pixel stride ldz.  The conv has no bias (norm follows). */
+ * z = relu?(BN(y) (+ residual)) with pixel stride ldz.  The conv has no bias (norm follows).
+ * z == NULL (residual must be NULL): only y and coeffs are produced; the consumer evaluates
+ * relu(BN(y)) in its operand loader (gs_conv_desc::in_affine = coeffs).  d->in_affine of THIS conv is
+ * honoured in forward and in the weight gradient of gs_conv_bn_backward. */
 int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const float* w, const gs_bn_args* bn,
                        const float* residual, int32_t ld_res, float* y, float* coeffs, float* z,
                        int32_t ldz, void* workspace, size_t workspace_bytes, void* stream);

@@ -49,9 +49,10 @@ def test_load_binds_and_reports_identity():
 
 
 def test_descriptor_struct_sizes_match_header():
-    # gs_conv_desc: 14 int32 + 4 int64 + 4 int32 ; gs_ce_desc: 6 int32 + 4 int64 + 2 int32
-    assert ctypes.sizeof(lib.ConvDesc) == 14 * 4 + 4 * 8 + 4 * 4
+    # gs_conv_desc: 14 int32 + 4 int64 + 4 int32 + 1 pointer ; gs_ce_desc: 6 int32 + 4 int64 + 2 int32
+    assert ctypes.sizeof(lib.ConvDesc) == 14 * 4 + 4 * 8 + 4 * 4 + 8
     assert ctypes.sizeof(lib.CeDesc) == 6 * 4 + 4 * 8 + 2 * 4
+    assert ctypes.sizeof(lib.SlideDesc) == 16 * 4
 
 
 def test_argument_validation_needs_no_gpu():

@@ -487,3 +487,75 @@ def test_syncbn_exchange_kernels_match_the_formula(hip_lib):
     assert float(m[:C].abs().max()) == 0.0
     assert torch.allclose(m[C:2 * C] / total, gvar, rtol=1e-5)
     assert torch.allclose(m[2 * C:], gmean, atol=1e-5)
+
+
+# BN + ReLU evaluated in the consumer's operand loaders (gs_conv_desc.in_affine): conv_a -> bn_a ->
+# relu -> conv_b -> bn_b with the intermediate activation deferred must equal the written-out form
+# bit for bit (same expression, same MFMA order), forward and backward, and match PyTorch on the CPU.
+DEFER_CASES = [
+    # ci  mid  co  kb  stride dil  n   h   w
+    (64, 64, 256, 1, 1, 1, 2, 40, 56),     # bn2 -> conv3 (1x1), several column tiles
+    (64, 48, 48, 3, 1, 1, 2, 33, 37),      # bn1 -> conv2 (3x3): padding must be zero AFTER the BN
+    (32, 96, 96, 3, 2, 1, 2, 32, 48),      # strided 3x3 (first block of a stage)
+    (32, 64, 64, 3, 1, 2, 1, 24, 24),      # dilated 3x3 (OS8 stages)
+    (16, 640, 80, 1, 1, 1, 2, 8, 12),      # widest operand (640 channels), long K: split-K wgrad
+    (16, 128, 64, 3, 1, 1, 2, 8, 8),       # 128 rows: split-K forward + paired K loop
+]
+
+
+@pytest.mark.parametrize("case", DEFER_CASES)
+def test_deferred_bn_relu_in_operand_loaders(hip_lib, case, monkeypatch):
+    import gaia_seg_amd.hip.ops as ops
+    from gaia_seg_amd.core.bricks import DynamicBatchNorm2d, DynamicConv2d, conv_bn_act
+    from gaia_seg_amd.hip.runtime import tape_function
+    ci, mid, co, kb, stride, dil, n, h, w = case
+    torch.manual_seed(5)
+    ca = DynamicConv2d(ci, mid, 1, bias=False)
+    ba = DynamicBatchNorm2d(mid)
+    cb = DynamicConv2d(mid, co, kb, stride=stride, padding=dil * (kb // 2), dilation=dil, bias=False)
+    bb = DynamicBatchNorm2d(co)
+    for c in (ca, cb):
+        torch.nn.init.normal_(c.weight, 0, 0.2)
+    for b in (ba, bb):
+        torch.nn.init.uniform_(b.weight, 0.5, 1.5)
+        torch.nn.init.normal_(b.bias, 0, 0.3)
+    x = torch.randn(n, ci, h, w) + 0.3
+
+    # CPU reference
+    xr = x.clone().requires_grad_(True)
+    pr = [p.detach().clone().contiguous().requires_grad_(True)
+          for p in (ca.weight, ba.weight, ba.bias, cb.weight, bb.weight, bb.bias)]
+    t = F.relu(F.batch_norm(F.conv2d(xr, pr[0]), None, None, pr[1], pr[2], True, 0.1, 1e-5))
+    z_ref = F.relu(F.batch_norm(F.conv2d(t, pr[3], None, stride, dil * (kb // 2), dil), None, None,
+                                pr[4], pr[5], True, 0.1, 1e-5))
+    gz = torch.randn_like(z_ref)
+    z_ref.backward(gz)
+
+    mods = [m.to(DEV) for m in (ca, ba, cb, bb)]
+    ca, ba, cb, bb = mods
+    ba.train(), bb.train()
+    results = []
+    for defer in (True, False):
+        monkeypatch.setattr(ops, "DEFER_BN", defer)
+        for m in mods:
+            for p in m.parameters():
+                p.grad = None
+        xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        seen = {}
+
+        def run(tape, acts):
+            mid_act = conv_bn_act(tape, ca, ba, acts[0], relu=True, defer=True)
+            seen["deferred"] = mid_act.affine is not None
+            return [conv_bn_act(tape, cb, bb, mid_act, relu=True)]
+        z = tape_function(run, [xg], True)[0]
+        assert seen["deferred"] == defer
+        z.backward(gz.to(DEV))
+        results.append([z.detach().clone(), xg.grad.clone()] +
+                       [p.grad.clone() for m in mods for p in m.parameters()])
+    for a, b in zip(*results):
+        assert torch.equal(a, b)            # loader fusion == written-out activation, bit for bit
+    z, dx, g_ca, g_baw, g_bab, g_cb, g_bbw, g_bbb = results[0]
+    assert rel_err(z, z_ref) < 1e-4
+    assert rel_err(dx, xr.grad) < 3e-4
+    for got, ref in zip((g_ca, g_baw, g_bab, g_cb, g_bbw, g_bbb), pr):
+        assert rel_err(got, ref.grad) < 3e-4
