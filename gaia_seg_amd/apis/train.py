@@ -102,6 +102,8 @@ def train_segmentor(model, train_sampler, val_sampler, dataset, cfg, distributed
         runner.resume(cfg.resume_from)
     elif cfg.get("load_from"):
         runner.load_checkpoint(cfg.load_from)
+    from .test import apply_bn_calibration
+    apply_bn_calibration(model, cfg.get("caliberate_bn"), "train")   # gaiaseg/apis/train.py:177-184
     loader = build_dataloader(dataset, cfg.data["samples_per_gpu"], seed=cfg.get("seed") or 0,
                               device=device)
     runner.run([loader], cfg.get("workflow", [("train", 1)]))

@@ -488,18 +488,22 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
         identity = x
         if self.downsample is not None:
             members = list(self.downsample)
+            if isinstance(members[0], nn.AvgPool2d):
+                # avg_down (dynamic_res_layer.py:75-82): AvgPool2d(stride, ceil_mode=True,
+                # count_include_pad=False) in front of a stride-1 1x1 conv
+                pool = members.pop(0)
+                k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+                st = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
+                if k != st or not pool.ceil_mode or pool.count_include_pad or pool.padding not in (0, (0, 0)):
+                    raise NotImplementedError("downsample AvgPool2d other than (k = stride, "
+                                              "ceil_mode=True, count_include_pad=False)")
+                identity = ops.avgpool_ceil(tape, identity, st) if st > 1 else identity
             if (len(members) == 2 and isinstance(members[0], DynamicConv2d)
                     and isinstance(members[1], DynamicBatchNorm2d)):
-                identity = conv_bn_act(tape, members[0], members[1], x, relu=False)
+                identity = conv_bn_act(tape, members[0], members[1], identity, relu=False)
             else:
-                for m in members:
-                    if isinstance(m, DynamicConv2d):
-                        identity = m.forward_act(tape, identity)
-                    elif isinstance(m, DynamicBatchNorm2d):
-                        identity = m.forward_act(tape, identity, relu=False)
-                    else:
-                        raise NotImplementedError("downsample member %s (avg_down) has no HIP "
-                                                  "kernel yet" % type(m).__name__)
+                raise NotImplementedError("downsample branch %s: expected [AvgPool2d,] conv, norm"
+                                          % [type(m).__name__ for m in self.downsample])
         # bn1 -> conv2 and bn2 -> conv3: the normalised activations are never stored; conv2 / conv3
         # (forward and weight gradient) evaluate relu(bn(.)) in their operand loaders
         out = conv_bn_act(tape, self.conv1, self.norm1, x, relu=True, defer=True)

@@ -74,6 +74,15 @@ def sync_module_states(model, arena=None, src=0):
                 off += b.numel()
 
 
+def gather_objects(obj):
+    """Every rank's python object, in rank order, on every rank (host group: no device sync)."""
+    if not is_dist():
+        return [obj]
+    out = [None] * world_size()
+    dist.all_gather_object(out, obj, group=_host_group())
+    return out
+
+
 _HOST_GROUP = None
 
 
@@ -177,10 +186,23 @@ class GradReducer:
         st["launched"][bi] = True
         if world_size() == 1:
             return
+        runs = st["plan"][bi]["runs"]
         if self.flat_grad.is_cuda:
+            # The bucket's weight gradients were queued on the side stream, its BN / bias gradients
+            # on the main stream.  The collective must wait for both, the MAIN stream for neither:
+            # the side stream takes a dependency on the main stream's work so far (one event) and
+            # the all-reduce is issued in the side stream's context — torch's RCCL backend makes its
+            # communication stream wait for the stream that is current at the call.  (r01 joined the
+            # side stream into the main stream here, which serialised backward behind every bucket.)
             from ..hip import ops as _ops
-            _ops.join_side_streams(self.flat_grad.device)  # wgrads of this bucket run on a side stream
-        for a, b in st["plan"][bi]["runs"]:
+            side = _ops.side_stream_after_main(self.flat_grad.device)
+            with torch.cuda.stream(side):
+                self._issue(runs)
+        else:
+            self._issue(runs)
+
+    def _issue(self, runs):
+        for a, b in runs:
             t = self.flat_grad[a:b]
             self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))

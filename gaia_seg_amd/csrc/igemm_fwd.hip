@@ -4,6 +4,7 @@
 using namespace gs;
 
 size_t gs_dgrad_strided_slab_bytes(const gs_conv_desc* d);  // igemm_dgrad.hip
+size_t gs_wgrad_slab_bytes(const gs_conv_desc* d);          // igemm_wgrad.hip
 #include "fused_internal.h"
 
 extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
@@ -18,10 +19,7 @@ extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
     b = std::max(b, slab_bytes(pl, (long)d->N * d->H * d->W, d->Ci));
     if (d->stride > 1) b = std::max(b, gs_dgrad_strided_slab_bytes(d));
   }
-  {
-    const Plan pl = plan_wgrad(d);
-    b = std::max(b, slab_bytes(pl, (long)d->KH * d->KW * d->Ci, d->Co));
-  }
+  b = std::max(b, gs_wgrad_slab_bytes(d));
   return b;
 }
 

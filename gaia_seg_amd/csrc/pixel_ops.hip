@@ -357,6 +357,47 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+// nn.AvgPool2d(kernel_size=s, stride=s, ceil_mode=True, count_include_pad=False): the pooling in
+// front of the 1x1 shortcut conv when avg_down=True (gaiaseg/models/utils/dynamic_res_layer.py:75-82).
+// Windows never overlap; a border window that ceil_mode lets hang over the image is averaged over
+// its in-bounds pixels only.  BWD = false: y = mean(window); BWD = true: dx = dy / count(window).
+template <bool BWD, bool ACC>
+__global__ __launch_bounds__(256) void avgpool_ceil_kernel(const float* __restrict__ src, int ld_src,
+                                                           int N, int H, int W, int C4, int s, int Ho,
+                                                           int Wo, float* dst, int ld_dst) {
+  const long total = (long)N * (BWD ? (long)H * W : (long)Ho * Wo) * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % C4);
+    long pix = i / C4;
+    if (BWD) {
+      const int w = (int)(pix % W);
+      pix /= W;
+      const int h = (int)(pix % H);
+      const int n = (int)(pix / H);
+      const int ho = h / s, wo = w / s;
+      const int cnt = (min(ho * s + s, H) - ho * s) * (min(wo * s + s, W) - wo * s);
+      f32x4 v = *reinterpret_cast<const f32x4*>(src + ((long)(n * Ho + ho) * Wo + wo) * ld_src + cq * 4);
+      v = v / (float)cnt;
+      float* o = dst + ((long)(n * H + h) * W + w) * ld_dst + cq * 4;
+      if (ACC) v += *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = v;
+    } else {
+      const int wo = (int)(pix % Wo);
+      pix /= Wo;
+      const int ho = (int)(pix % Ho);
+      const int n = (int)(pix / Ho);
+      const int h1 = min(ho * s + s, H), w1 = min(wo * s + s, W);
+      f32x4 acc{0.f, 0.f, 0.f, 0.f};
+      for (int h = ho * s; h < h1; ++h)
+        for (int w = wo * s; w < w1; ++w)
+          acc += *reinterpret_cast<const f32x4*>(src + ((long)(n * H + h) * W + w) * ld_src + cq * 4);
+      acc = acc / (float)((h1 - ho * s) * (w1 - wo * s));
+      *reinterpret_cast<f32x4*>(dst + ((long)(n * Ho + ho) * Wo + wo) * ld_dst + cq * 4) = acc;
+    }
+  }
+}
+
 static int check_nhwc(const void* p, int C, int ld) {
   if (!p) return GS_E_NULL;
   if (C <= 0) return GS_E_BADARG;
@@ -427,6 +468,38 @@ static int avgpool_splits(int N, int H, int W, int C, int total_bins) {
   if (want > max_by_px) want = max_by_px;
   if (want > 32) want = 32;
   return (int)std::max<long>(want, 1);
+}
+
+extern "C" int gs_avgpool_ceil_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,
+                                       int32_t ldx, int32_t s, float* y, int32_t ldy, void* stream) {
+  int rc = check_nhwc(x, C, ldx);
+  if (rc) return rc;
+  if ((rc = check_nhwc(y, C, ldy))) return rc;
+  if (N <= 0 || H <= 0 || W <= 0 || s <= 0) return GS_E_BADARG;
+  const int Ho = (H + s - 1) / s, Wo = (W + s - 1) / s;
+  const long total = (long)N * Ho * Wo * (C >> 2);
+  hipLaunchKernelGGL((avgpool_ceil_kernel<false, false>), dim3(stream_grid(total, 256)), dim3(256), 0,
+                     as_stream(stream), x, ldx, N, H, W, C >> 2, s, Ho, Wo, y, ldy);
+  return launch_status();
+}
+
+extern "C" int gs_avgpool_ceil_backward(const float* dy, int32_t ld_dy, int32_t N, int32_t H, int32_t W,
+                                        int32_t C, int32_t s, float* dx, int32_t ld_dx,
+                                        int32_t accumulate, void* stream) {
+  int rc = check_nhwc(dy, C, ld_dy);
+  if (rc) return rc;
+  if ((rc = check_nhwc(dx, C, ld_dx))) return rc;
+  if (N <= 0 || H <= 0 || W <= 0 || s <= 0) return GS_E_BADARG;
+  const int Ho = (H + s - 1) / s, Wo = (W + s - 1) / s;
+  const long total = (long)N * H * W * (C >> 2);
+  const dim3 grid(stream_grid(total, 256));
+  if (accumulate)
+    hipLaunchKernelGGL((avgpool_ceil_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), dy,
+                       ld_dy, N, H, W, C >> 2, s, Ho, Wo, dx, ld_dx);
+  else
+    hipLaunchKernelGGL((avgpool_ceil_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), dy,
+                       ld_dy, N, H, W, C >> 2, s, Ho, Wo, dx, ld_dx);
+  return launch_status();
 }
 
 extern "C" size_t gs_adaptive_avgpool_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C,

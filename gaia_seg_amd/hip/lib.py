@@ -84,6 +84,8 @@ PROTOTYPES = {
                                 _P, _sz, _P]),
     "gs_bn_bwd_apply": (_i32, [_P, _i32, _P, _i32, _P, _i32, _i64, _i32, _P, _P, _f64, _i32, _i32,
                                _P, _i32, _P, _P, _P]),
+    "gs_avgpool_ceil_forward": (_i32, [_P, _i32, _i32, _i32, _i32, _i32, _i32, _P, _i32, _P]),
+    "gs_avgpool_ceil_backward": (_i32, [_P, _i32, _i32, _i32, _i32, _i32, _i32, _P, _i32, _i32, _P]),
     "gs_maxpool_forward": (_i32, [_P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                   _P, _i32, _P, _P]),
     "gs_maxpool_backward": (_i32, [_P, _i32, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,

@@ -46,6 +46,15 @@ def join_side_streams(dev=None):
             _side_dirty[key] = False
 
 
+def side_stream_after_main(dev):
+    """The side stream, made to wait for everything queued on the current (main) stream so far."""
+    s = _side_stream(dev)
+    with torch.cuda.device(dev):
+        _lib.check(_L().gs_stream_fork(current_stream_ptr(), s.cuda_stream), "gs_stream_fork")
+    _side_dirty[(dev.type, dev.index)] = True   # the main stream joins it at the end of backward
+    return s
+
+
 def _side_workspace(need, dev, side):
     """Split-K scratch of the side stream (allocated under that stream, so the caching allocator
     orders its reuse against the side stream's kernels)."""
@@ -591,6 +600,31 @@ def maxpool(tape, x, k=3, s=2, p=1):
                                          x.C, k, s, p, ho, wo, x.g.data_ptr(), x.g.stride(2),
                                          1 if acc else 0, current_stream_ptr()),
                    "gs_maxpool_backward")
+
+    tape.record(backward)
+    return out
+
+
+def avgpool_ceil(tape, x, s):
+    """nn.AvgPool2d(s, stride=s, ceil_mode=True, count_include_pad=False) (avg_down shortcut)."""
+    L = _L()
+    x = materialize(tape, x)
+    dev = x.t.device
+    ho, wo = (x.H + s - 1) // s, (x.W + s - 1) // s
+    out = Act.empty(x.N, ho, wo, x.C, dev)
+    _lib.check(L.gs_avgpool_ceil_forward(x.ptr, x.N, x.H, x.W, x.C, x.ld, s, out.ptr, out.ld,
+                                         current_stream_ptr()), "gs_avgpool_ceil_forward")
+
+    def backward():
+        dy = out.g
+        if dy is None or not x.requires_grad:
+            return
+        acc = x.g is not None
+        if not acc:
+            x.new_grad() if x.parent is None else _alloc_parent_grad(x)
+        _lib.check(L.gs_avgpool_ceil_backward(dy.data_ptr(), dy.stride(2), x.N, x.H, x.W, x.C, s,
+                                              x.g.data_ptr(), x.g.stride(2), 1 if acc else 0,
+                                              current_stream_ptr()), "gs_avgpool_ceil_backward")
 
     tape.record(backward)
     return out

@@ -232,6 +232,15 @@ int gs_k3_timer_read(int64_t* launches, double* total_ms, double* total_flops);
 /* ------------------------------------------------------------------------------------------ */
 /* Pooling — K5, K7                                                                            */
 /* ------------------------------------------------------------------------------------------ */
+/* nn.AvgPool2d(kernel_size=s, stride=s, ceil_mode=True, count_include_pad=False): the shortcut
+ * pooling of avg_down=True (gaiaseg/models/utils/dynamic_res_layer.py:75-82).  Output size
+ * ceil(H/s) x ceil(W/s); border windows average their in-bounds pixels only.
+ * backward: dx[n,h,w,:] (+)= dy[n,h/s,w/s,:] / count(window). */
+int gs_avgpool_ceil_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                            int32_t s, float* y, int32_t ldy, void* stream);
+int gs_avgpool_ceil_backward(const float* dy, int32_t ld_dy, int32_t N, int32_t H, int32_t W,
+                             int32_t C, int32_t s, float* dx, int32_t ld_dx, int32_t accumulate,
+                             void* stream);
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (dynamic_resnet.py:302,413), generic k/s/p.
  * idx (uint8 tap index of the first maximum in (kh,kw) scan order, as ATen) is saved for bwd. */
 int gs_maxpool_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,

@@ -102,7 +102,9 @@ class OBottleneck(nn.Module):
         self.conv2.manipulate_width(w)
         self.conv3.manipulate_width(4 * w)
         if self.downsample is not None:
-            self.downsample[0].manipulate_width(4 * w)
+            for m in self.downsample:
+                if isinstance(m, OConv):
+                    m.manipulate_width(4 * w)
 
     def forward(self, x):
         identity = x
@@ -115,11 +117,17 @@ class OBottleneck(nn.Module):
 
 
 class OResLayer(nn.ModuleList):
-    def __init__(self, inplanes, planes, depth, stride=1, dilation=1, contract_dilation=False):
+    def __init__(self, inplanes, planes, depth, stride=1, dilation=1, contract_dilation=False,
+                 avg_down=False):
         downsample = None
-        if stride != 1 or inplanes != planes * 4:  # dynamic_res_layer.py:70-94 (avg_down=False)
-            downsample = nn.Sequential(OConv(inplanes, planes * 4, 1, stride=stride, bias=False),
-                                       OBN(planes * 4))
+        if stride != 1 or inplanes != planes * 4:  # dynamic_res_layer.py:70-94
+            mods, conv_stride = [], stride
+            if avg_down:                            # :75-82
+                conv_stride = 1
+                mods.append(nn.AvgPool2d(kernel_size=stride, stride=stride, ceil_mode=True,
+                                         count_include_pad=False))
+            mods += [OConv(inplanes, planes * 4, 1, stride=conv_stride, bias=False), OBN(planes * 4)]
+            downsample = nn.Sequential(*mods)
         first_dilation = dilation // 2 if (dilation > 1 and contract_dilation) else dilation
         layers = [OBottleneck(inplanes, planes, stride, first_dilation, downsample)]
         for _ in range(1, depth):
@@ -136,7 +144,7 @@ class OResLayer(nn.ModuleList):
 class ODynamicResNet(nn.Module):
     def __init__(self, in_channels, stem_width, body_width, body_depth, strides=(1, 2, 2, 2),
                  dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), deep_stem=False,
-                 contract_dilation=False, **unused):
+                 contract_dilation=False, avg_down=False, **unused):
         super().__init__()
         self.deep_stem = deep_stem
         self.out_indices = out_indices
@@ -156,7 +164,7 @@ class ODynamicResNet(nn.Module):
         self.res_layers = []
         for i, depth in enumerate(body_depth):
             layer = OResLayer(inplanes, body_width[i], depth, strides[i], dilations[i],
-                              contract_dilation)
+                              contract_dilation, avg_down)
             inplanes = body_width[i] * 4
             name = "layer%d" % (i + 1)
             self.add_module(name, layer)

@@ -58,6 +58,12 @@ CONV_CASES = [
     (32, 32, 32, 32, 3, 1, 2, 2, 1, 12, 12),
     (64, 320, 64, 256, 1, 2, 0, 1, 2, 15, 15),
     (3, 64, 3, 32, 7, 2, 3, 1, 2, 32, 40),
+    # 3x3 stride 1, W % 16 == 0: weight gradient through the all-taps kernel (wgrad_taps.h)
+    (64, 64, 64, 64, 3, 1, 1, 1, 2, 24, 32),       # one 64-channel block, 2 column strips
+    (80, 80, 80, 80, 3, 1, 1, 1, 2, 12, 16),       # ci blocks 48 + 32, co blocks 64 + 16
+    (160, 96, 160, 48, 3, 1, 1, 1, 1, 9, 48),      # 3 ci blocks (64, 64, 32), ragged co
+    (320, 320, 192, 320, 3, 1, 1, 1, 2, 6, 16),    # leading slice of a wider weight, 5 co blocks
+    (48, 48, 48, 48, 3, 1, 1, 1, 2, 130, 64),      # many rows: several row ranges per strip
     (3, 32, 3, 24, 3, 2, 1, 1, 2, 17, 19),
     (24, 48, 24, 48, 3, 1, 1, 1, 1, 9, 9),
     (512, 128, 512, 128, 3, 1, 1, 1, 2, 8, 8),
@@ -500,6 +506,8 @@ DEFER_CASES = [
     (32, 64, 64, 3, 1, 2, 1, 24, 24),      # dilated 3x3 (OS8 stages)
     (16, 640, 80, 1, 1, 1, 2, 8, 12),      # widest operand (640 channels), long K: split-K wgrad
     (16, 128, 64, 3, 1, 1, 2, 8, 8),       # 128 rows: split-K forward + paired K loop
+    (32, 80, 64, 3, 1, 1, 2, 20, 32),      # W % 16 == 0: all-taps wgrad with the affine loader
+    (32, 64, 48, 3, 1, 1, 2, 40, 16),      # all-taps wgrad, one strip per image, row ranges
 ]
 
 

@@ -54,6 +54,13 @@ def test_uper_supernet_train_step(hip_lib, arch):
     _run_pair(model_cfg(uper_head(), aux=False), arch, size=(97, 97))
 
 
+def test_fcn_avg_down_shortcuts(hip_lib):
+    """avg_down=True (dynamic_res_layer.py:75-82): AvgPool2d(ceil_mode, count_include_pad=False)
+    + stride-1 1x1 shortcut; 63x95 makes every pooled border window ragged."""
+    _run_pair(model_cfg(fcn_head(), aux=True, deep_stem=True, avg_down=True), "sub", deep_stem=True,
+              size=(63, 95))
+
+
 def test_backbone_features_and_depth_prefix(hip_lib):
     """depth d == first d blocks; features equal the oracle's on every output level."""
     prod, orc = make_pair(model_cfg(fcn_head(), aux=False))

@@ -6,7 +6,7 @@ import torch
 CONV = dict(type="DynConv2d")
 
 
-def tiny_backbone(deep_stem=False, os8=False, norm="DynSyncBN"):
+def tiny_backbone(deep_stem=False, os8=False, norm="DynSyncBN", avg_down=False):
     cfg = dict(type="DynamicResNet", in_channels=3,
                stem_width=[16, 16, 32] if deep_stem else 32,
                body_depth=[2, 2, 3, 2], body_width=[32, 64, 96, 128], num_stages=4,
@@ -15,6 +15,8 @@ def tiny_backbone(deep_stem=False, os8=False, norm="DynSyncBN"):
                else dict(type=norm, requires_grad=True), style="pytorch", deep_stem=deep_stem)
     if os8:
         cfg.update(strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4), contract_dilation=True)
+    if avg_down:
+        cfg.update(avg_down=True)
     return cfg
 
 
