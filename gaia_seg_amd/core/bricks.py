@@ -504,10 +504,12 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
             else:
                 raise NotImplementedError("downsample branch %s: expected [AvgPool2d,] conv, norm"
                                           % [type(m).__name__ for m in self.downsample])
-        # bn1 -> conv2 and bn2 -> conv3: the normalised activations are never stored; conv2 / conv3
-        # (forward and weight gradient) evaluate relu(bn(.)) in their operand loaders
-        out = conv_bn_act(tape, self.conv1, self.norm1, x, relu=True, defer=True)
-        out = conv_bn_act(tape, self.conv2, self.norm2, out, relu=True, tag="k3", defer=True)  # K3
+        # bn1 -> conv2 / bn2 -> conv3 (ops.DEFER_EDGES): the normalised activation is never stored;
+        # the consumer (forward and weight gradient) evaluates relu(bn(.)) in its operand loaders
+        out = conv_bn_act(tape, self.conv1, self.norm1, x, relu=True,
+                          defer="conv2" in ops.DEFER_EDGES)
+        out = conv_bn_act(tape, self.conv2, self.norm2, out, relu=True, tag="k3",
+                          defer="conv3" in ops.DEFER_EDGES)
         return conv_bn_act(tape, self.conv3, self.norm3, out, relu=True, residual=identity)
 
     def forward(self, x):

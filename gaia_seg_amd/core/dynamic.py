@@ -39,6 +39,22 @@ class DynamicMixin:
         return self
 
 
+def unzip_meta(meta):
+    """Per-child view of a dict of equally long lists:
+    {'width': [a, b], 'depth': [c, d]} -> [{'width': a, 'depth': c}, {'width': b, 'depth': d}]
+    (what DynamicResNet hands to its stem convs / stages, dynamic_resnet.py:381-403)."""
+    keys = list(meta)
+    return [dict(zip(keys, vals)) for vals in zip(*(meta[k] for k in keys))]
+
+
+def freeze(module):
+    """Take a module out of training: eval mode (BatchNorm uses its running statistics) and no
+    gradients for its parameters."""
+    module.eval()
+    for p in module.parameters():
+        p.requires_grad = False
+
+
 def fold_dict(flat, sep="."):
     """{'arch.backbone.body.width': [..]} -> {'arch': {'backbone': {'body': {'width': [..]}}}}."""
     out = {}

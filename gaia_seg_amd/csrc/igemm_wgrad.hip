@@ -1,42 +1,12 @@
 // DynConv2d weight gradient (implicit GEMM over pixels, split-K) — see igemm_core.h
 #include "igemm_core.h"
-#include "wgrad_taps.h"
 
 using namespace gs;
 
-// slab bytes of the weight-gradient path gs_conv2d_wgrad will take for this descriptor
+// slab bytes of the weight-gradient path gs_conv2d_wgrad takes for this descriptor
 size_t gs_wgrad_slab_bytes(const gs_conv_desc* d) {
-  const Plan pl = plan_wgrad(d);   // (also the fallback when a plan is forced by the tuning hook)
-  size_t b = slab_bytes(pl, (long)d->KH * d->KW * d->Ci, d->Co);
-  if (wgrad_taps_ok(d)) b = std::max(b, wgrad_taps_slab_bytes(d));
-  return b;
-}
-
-static int wgrad_taps(const gs_conv_desc* d, const float* x, const float* dy, float* dw,
-                      void* workspace, size_t workspace_bytes, hipStream_t st) {
-  const WgTapsPlan pl = wgrad_taps_plan(d);
-  const size_t need = pl.nsplit > 1 ? (size_t)pl.nsplit * 9 * d->Ci * d->Co * sizeof(float) : 0;
-  if (need > workspace_bytes || (need && !workspace)) return GS_E_WORKSPACE;
-  WgTapsArgs a{};
-  a.x = x; a.dy = dy; a.out = dw; a.slab = need ? static_cast<float*>(workspace) : nullptr;
-  a.a_coeffs = d->in_affine;
-  a.xs_n = d->x_sn; a.xs_h = d->x_sh; a.xs_w = d->x_sw;
-  a.N = d->N; a.H = d->H; a.W = d->W; a.Ci = d->Ci; a.Co = d->Co; a.ld_dy = d->ldy;
-  a.cb = pl.cb; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.wseg = d->W / 16;
-  a.rows_per_split = pl.rows_per_split; a.hsplits = pl.hsplits;
-  a.o_tap = (long)d->Ci_max * d->Co_ld; a.o_row = d->Co_ld;
-  a.x_bytes = (unsigned)((size_t)d->N * d->x_sn * sizeof(float));
-  a.dy_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->ldy * sizeof(float));
-  const dim3 grid(pl.tiles_m * pl.tiles_n * pl.nsplit), block(NT);
-  if (d->in_affine) hipLaunchKernelGGL(wgrad_taps_kernel<true>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(wgrad_taps_kernel<false>, grid, block, 0, st, a);
-  int rc = launch_status();
-  if (rc != GS_OK || pl.nsplit == 1) return rc;
-  IgemmArgs r{};   // the tap-major kernel's slab layout and fixed-order reduce
-  r.slab = a.slab; r.out = dw; r.M = 9 * d->Ci; r.Nn = d->Co; r.Cs = d->Ci;
-  r.o_tap = a.o_tap; r.o_row = a.o_row;
-  launch_reduce(r, pl.nsplit, 1, st);
-  return launch_status();
+  const Plan pl = plan_wgrad(d);
+  return slab_bytes(pl, (long)d->KH * d->KW * d->Ci, d->Co);
 }
 
 extern "C" int gs_conv2d_wgrad(const gs_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -47,10 +17,6 @@ extern "C" int gs_conv2d_wgrad(const gs_conv_desc* d, const float* x, const floa
   if (!aligned16(dy) || !aligned16(dw)) return GS_E_ALIGN;
   const bool vec = x_is_vector(d);
   if (vec && !aligned16(x)) return GS_E_ALIGN;
-  if (wgrad_taps_ok(d) && g_force_plan[0] == 0) {
-    if (d->in_affine && (!conv_in_affine_ok(d) || !aligned16(d->in_affine))) return GS_E_BADARG;
-    return wgrad_taps(d, x, dy, dw, workspace, workspace_bytes, as_stream(stream));
-  }
   const Plan pl = plan_wgrad(d);
   const long M = (long)d->KH * d->KW * d->Ci;
   const size_t need = slab_bytes(pl, M, d->Co);

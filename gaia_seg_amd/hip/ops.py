@@ -171,7 +171,15 @@ def _trace_relu_deferred(bn, y, coeffs):
         RELU_TRACE.append((bn.weight, tmp.t > 0))
 
 
-DEFER_BN = os.environ.get("GS_NO_DEFER_BN") is None   # bn1 -> conv2 / bn2 -> conv3 loader fusion
+# Loader fusion of BN + ReLU into the consumer convolution (gs_conv_desc.in_affine).  Which edges of
+# a bottleneck use it: "conv3" = bn2 -> conv3 (1x1), "conv2" = bn1 -> conv2 (the 3x3, K3).
+# GS_DEFER_BN = comma list, "all" or "none".  r02 A/B on the sampled mix (bench.py, 30 steps):
+# none 145.5 img/s, K3 at 0.555 of peak; all 145.4 img/s, K3 at 0.500 (the affine + select in the
+# store slot of the K loop costs the 3x3 what the two removed bn_apply launches save); the default
+# keeps the headline 3x3 kernel free of it.
+_defer = os.environ.get("GS_DEFER_BN", "conv3").lower()
+DEFER_EDGES = {"all": {"conv2", "conv3"}, "none": set()}.get(_defer, set(_defer.split(",")))
+DEFER_BN = True   # master switch (tests flip it to compare the two forms bit for bit)
 
 
 def materialize(tape, x):

@@ -11,7 +11,7 @@ from torch.nn.modules.batchnorm import _BatchNorm
 
 from ...core.bricks import (DynamicBatchNorm2d, DynamicBottleneck, DynamicConv2d,
                             build_conv_layer, build_norm_layer, constant_init, kaiming_init)
-from ...core.dynamic import DynamicMixin
+from ...core.dynamic import DynamicMixin, freeze, unzip_meta
 from ...hip import ops
 from ...hip.runtime import tape_function
 from ..builder import BACKBONES
@@ -78,7 +78,6 @@ class DynamicResNet(nn.Module, DynamicMixin):
             self.res_layers.append(layer_name)
 
         self._freeze_stages()
-        self._freeze_layers()
         self.feat_dim = self.block.expansion * body_width[0] * 2 ** (len(self.body_depth) - 1)
         self.active_feat_dim = self.feat_dim
 
@@ -114,80 +113,71 @@ class DynamicResNet(nn.Module, DynamicMixin):
             self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
 
-    def _freeze_stages(self):
+    # ---- freezing (frozen_stages / frozen_layers, dynamic_resnet.py:304-334) ----
+    def _frozen_modules(self):
+        """frozen_stages = k >= 0 freezes the stem and stages 1..k; frozen_layers[i] = m freezes the
+        first m blocks of stage i."""
+        mods = []
         if self.frozen_stages >= 0:
-            if self.deep_stem:
-                self.stem.eval()
-                for param in self.stem.parameters():
-                    param.requires_grad = False
-            else:
-                self.norm1.eval()
-                for m in [self.conv1, self.norm1]:
-                    for param in m.parameters():
-                        param.requires_grad = False
-        for i in range(1, self.frozen_stages + 1):
-            m = getattr(self, "layer%d" % i)
-            m.eval()
-            for param in m.parameters():
-                param.requires_grad = False
-
-    def _freeze_layers(self):
+            mods += [self.stem] if self.deep_stem else [self.conv1, self.norm1]
+            mods += [getattr(self, name) for name in self.res_layers[:self.frozen_stages]]
         if self.frozen_layers is not None:
-            for i, layer_name in enumerate(self.res_layers):
-                res_layer = getattr(self, layer_name)
-                frozen_layer_num = self.frozen_layers[i]
-                assert frozen_layer_num <= len(res_layer)
-                for j in range(frozen_layer_num):
-                    m = res_layer[j]
-                    m.eval()
-                    for param in m.parameters():
-                        param.requires_grad = False
+            for name, count in zip(self.res_layers, self.frozen_layers):
+                layer = getattr(self, name)
+                if count > len(layer):
+                    raise ValueError("frozen_layers asks for %d blocks of %s, which has %d"
+                                     % (count, name, len(layer)))
+                mods += list(layer[:count])
+        return mods
+
+    def _freeze_stages(self):
+        for m in self._frozen_modules():
+            freeze(m)
+
+    _freeze_layers = _freeze_stages   # one pass covers both options (kept for API parity)
 
     def init_weights(self, pretrained=None):
-        # dynamic_resnet.py:336-367
+        """He-normal convs, unit norms, zero last norm of every bottleneck (zero_init_residual), or a
+        checkpoint path (dynamic_resnet.py:336-367)."""
         if isinstance(pretrained, str):
             from ...core.checkpoint import load_checkpoint
             load_checkpoint(self, pretrained, strict=False)
-        elif pretrained is None:
-            for m in self.modules():
-                if isinstance(m, DynamicConv2d):
-                    kaiming_init(m)
-                elif isinstance(m, (_BatchNorm, nn.GroupNorm)):
-                    constant_init(m, 1)
-            if self.zero_init_residual:
-                for m in self.modules():
-                    if isinstance(m, DynamicBottleneck):
-                        constant_init(m.norm3, 0)
-        else:
+            return
+        if pretrained is not None:
             raise TypeError("pretrained must be a str or None")
+        last_norms = {id(m.norm3) for m in self.modules()
+                      if isinstance(m, DynamicBottleneck)} if self.zero_init_residual else set()
+        for m in self.modules():
+            if isinstance(m, DynamicConv2d):
+                kaiming_init(m)
+            elif isinstance(m, (_BatchNorm, nn.GroupNorm)):
+                constant_init(m, 0 if id(m) in last_norms else 1)
 
     def train(self, mode=True):
         super().train(mode)
         self._freeze_stages()
-        self._freeze_layers()
-        if mode and self.norm_eval:
+        if mode and self.norm_eval:   # BatchNorm keeps its running statistics while training
             for m in self.modules():
                 if isinstance(m, _BatchNorm):
                     m.eval()
         return self
 
+    # ---- arch manipulation (dynamic_resnet.py:381-403) ----
+    def _stem_convs(self):
+        return [self.stem[0], self.stem[3], self.stem[6]] if self.deep_stem else [self.conv1]
+
     def manipulate_stem(self, arch_meta):
-        # dynamic_resnet.py:381-395
+        """{'width': 32}, or {'width': [16, 16, 32]} for the three convs of a deep stem."""
         self.stem_state = arch_meta
-        if self.deep_stem:
-            sliced = [dict(zip(arch_meta, t)) for t in zip(*arch_meta.values())]
-            self.stem[0].manipulate_arch(sliced[0])
-            self.stem[3].manipulate_arch(sliced[1])
-            self.stem[6].manipulate_arch(sliced[2])
-        else:
-            self.conv1.manipulate_arch(arch_meta)
+        metas = unzip_meta(arch_meta) if self.deep_stem else [arch_meta]
+        for conv, meta in zip(self._stem_convs(), metas):
+            conv.manipulate_arch(meta)
 
     def manipulate_body(self, arch_meta):
-        # dict of lists -> list of dicts, dynamic_resnet.py:397-403
+        """{'width': [w1..w4], 'depth': [d1..d4]}: one entry per stage."""
         self.body_state = arch_meta
-        sliced = [dict(zip(arch_meta, t)) for t in zip(*arch_meta.values())]
-        for i, layer_name in enumerate(self.res_layers):
-            getattr(self, layer_name).manipulate_arch(sliced[i])
+        for name, meta in zip(self.res_layers, unzip_meta(arch_meta)):
+            getattr(self, name).manipulate_arch(meta)
 
     # ---- execution ----
     def forward_act(self, tape, x):

@@ -37,21 +37,7 @@ class DynamicResLayer(nn.ModuleList, DynamicMixin):
         self.avg_down = avg_down
         self.init_state(depth=depth, width=planes)
 
-        # downsample branch: dynamic_res_layer.py:70-94
-        downsample = None
-        if stride != 1 or inplanes != planes * block.expansion:
-            downsample = []
-            conv_stride = stride
-            if avg_down:
-                conv_stride = 1
-                downsample.append(nn.AvgPool2d(kernel_size=stride, stride=stride, ceil_mode=True,
-                                               count_include_pad=False))
-            downsample.extend([
-                build_conv_layer(conv_cfg, inplanes, planes * block.expansion, kernel_size=1,
-                                 padding=0, stride=conv_stride, bias=False),
-                build_norm_layer(norm_cfg, planes * block.expansion)[1]
-            ])
-            downsample = nn.Sequential(*downsample)
+        downsample = self._shortcut(block, inplanes, planes, stride, avg_down, conv_cfg, norm_cfg)
 
         # contract_dilation: dynamic_res_layer.py:98-102
         first_dilation = dilation // 2 if (dilation > 1 and contract_dilation) else dilation
@@ -65,6 +51,23 @@ class DynamicResLayer(nn.ModuleList, DynamicMixin):
             layers.append(block(inplanes=inplanes, planes=planes, stride=1, dilation=dilation,
                                 conv_cfg=conv_cfg, norm_cfg=norm_cfg, **kwargs))
         super().__init__(layers)
+
+    @staticmethod
+    def _shortcut(block, inplanes, planes, stride, avg_down, conv_cfg, norm_cfg):
+        """Projection shortcut of the first block (dynamic_res_layer.py:70-94): needed when the block
+        changes resolution or width.  avg_down moves the stride into an AvgPool2d(ceil_mode,
+        count_include_pad=False) in front of a stride-1 1x1 conv."""
+        out_planes = planes * block.expansion
+        if stride == 1 and inplanes == out_planes:
+            return None
+        mods = []
+        if avg_down:
+            mods.append(nn.AvgPool2d(kernel_size=stride, stride=stride, ceil_mode=True,
+                                     count_include_pad=False))
+        mods.append(build_conv_layer(conv_cfg, inplanes, out_planes, kernel_size=1, padding=0,
+                                     stride=1 if avg_down else stride, bias=False))
+        mods.append(build_norm_layer(norm_cfg, out_planes)[1])
+        return nn.Sequential(*mods)
 
     def manipulate_depth(self, depth):
         assert depth >= 1, "Depth must be greater than 0, skipping stage is not supported yet."

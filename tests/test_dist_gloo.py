@@ -122,3 +122,21 @@ def test_manipulate_arch_hook_broadcasts_rank0_draw():
 def test_syncbn_statistics_merge_matches_global_batch():
     out = _run(_worker_syncbn)
     assert all(ok for _, ok in out), out
+
+
+def _worker_collect(rank, world, port, q):
+    _init(rank, world, port)
+    from gaia_seg_amd.apis.test import collect_results
+    size = 7                                  # 7 samples over 2 ranks: the sampler pads rank 1
+    mine = ["sample%d" % i for i in range(rank, 8, world)]   # rank r holds r, r + world, ...
+    got = collect_results(mine, size)
+    q.put((rank, got))
+    dist.destroy_process_group()
+
+
+def test_collect_results_restores_dataset_order():
+    """gaiaseg/apis/test.py:113-186: rank 0 gets every rank's results interleaved in dataset order
+    and truncated to the dataset size; other ranks get None."""
+    out = _run(_worker_collect)
+    assert out[0][1] == ["sample%d" % i for i in range(7)]
+    assert out[1][1] is None

@@ -58,7 +58,7 @@ CONV_CASES = [
     (32, 32, 32, 32, 3, 1, 2, 2, 1, 12, 12),
     (64, 320, 64, 256, 1, 2, 0, 1, 2, 15, 15),
     (3, 64, 3, 32, 7, 2, 3, 1, 2, 32, 40),
-    # 3x3 stride 1, W % 16 == 0: weight gradient through the all-taps kernel (wgrad_taps.h)
+    # 3x3 stride 1, wide / ragged channel blocks, leading slices of wider weights
     (64, 64, 64, 64, 3, 1, 1, 1, 2, 24, 32),       # one 64-channel block, 2 column strips
     (80, 80, 80, 80, 3, 1, 1, 1, 2, 12, 16),       # ci blocks 48 + 32, co blocks 64 + 16
     (160, 96, 160, 48, 3, 1, 1, 1, 1, 9, 48),      # 3 ci blocks (64, 64, 32), ragged co
@@ -506,8 +506,8 @@ DEFER_CASES = [
     (32, 64, 64, 3, 1, 2, 1, 24, 24),      # dilated 3x3 (OS8 stages)
     (16, 640, 80, 1, 1, 1, 2, 8, 12),      # widest operand (640 channels), long K: split-K wgrad
     (16, 128, 64, 3, 1, 1, 2, 8, 8),       # 128 rows: split-K forward + paired K loop
-    (32, 80, 64, 3, 1, 1, 2, 20, 32),      # W % 16 == 0: all-taps wgrad with the affine loader
-    (32, 64, 48, 3, 1, 1, 2, 40, 16),      # all-taps wgrad, one strip per image, row ranges
+    (32, 80, 64, 3, 1, 1, 2, 20, 32),      # ragged 80-channel operand with the affine loader
+    (32, 64, 48, 3, 1, 1, 2, 40, 16),      # narrow image, many rows
 ]
 
 
@@ -552,7 +552,7 @@ def test_deferred_bn_relu_in_operand_loaders(hip_lib, case, monkeypatch):
         seen = {}
 
         def run(tape, acts):
-            mid_act = conv_bn_act(tape, ca, ba, acts[0], relu=True, defer=True)
+            mid_act = conv_bn_act(tape, ca, ba, acts[0], relu=True, defer=True)  # (explicit: not via DEFER_EDGES)
             seen["deferred"] = mid_act.affine is not None
             return [conv_bn_act(tape, cb, bb, mid_act, relu=True)]
         z = tape_function(run, [xg], True)[0]

@@ -163,3 +163,23 @@ def test_closed_form_flops_match_baseline_table(psp_model):
         assert abs(f["backbone_3x3"] / 1e9 - k3) < 0.06
         assert abs(f["backbone_params"] / 1e6 - params) < 0.02
         assert abs(f["decode"] / 1e9 - psp) < 0.06 and abs(f["aux"] / 1e9 - aux) < 0.06
+
+
+def test_bn_calibration_switches():
+    """cfg.caliberate_bn: reset_stats before training (gaiaseg/apis/train.py:177-184) and
+    use_minibatch_stats at test time (tools/test_supernet.py:190-198)."""
+    import torch
+    from gaia_seg_amd.apis.test import apply_bn_calibration
+    from gaia_seg_amd.core.bricks import DynamicBatchNorm2d
+    net = torch.nn.Sequential(DynamicBatchNorm2d(8), torch.nn.ReLU(), DynamicBatchNorm2d(4))
+    for m in (net[0], net[2]):
+        m.running_mean.normal_()
+        m.running_var.uniform_(0.5, 2.0)
+    assert apply_bn_calibration(net, None, "train") == 0
+    assert apply_bn_calibration(net, dict(reset_stats=True), "test") == 0      # wrong phase: no-op
+    assert apply_bn_calibration(net, dict(reset_stats=True), "train") == 2
+    assert float(net[0].running_mean.abs().max()) == 0.0 and float((net[2].running_var - 1).abs().max()) == 0.0
+    assert apply_bn_calibration(net, dict(use_minibatch_stats=True), "test") == 2
+    assert net[0].running_mean is None and net[0].track_running_stats is False
+    # eval-mode BN without running statistics normalises with the batch it sees
+    assert net[0].eval().bn_params(8).running_mean is None
