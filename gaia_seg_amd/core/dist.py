@@ -195,6 +195,7 @@ class GradReducer:
             # communication stream wait for the stream that is current at the call.  (r01 joined the
             # side stream into the main stream here, which serialised backward behind every bucket.)
             from ..hip import ops as _ops
+            _ops.flush_wgrads()   # (no-op when this call comes from a flush: the queue is already empty)
             side = _ops.side_stream_after_main(self.flat_grad.device)
             with torch.cuda.stream(side):
                 self._issue(runs)

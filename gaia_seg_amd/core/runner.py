@@ -81,13 +81,31 @@ class ArenaOptimizerHook(Hook):
             raise NotImplementedError("grad_clip is not configured by the in-tree configs")
 
     def after_train_iter(self, runner):
+        from ..hip import ops
         prof = runner.host_prof
         t0 = time.perf_counter() if prof is not None else 0.0
-        runner.outputs["loss"].backward()
+        ops.SIDE_CHECKPOINT = None
+        ops.DEFER_JOIN = True          # the tapes hand their weight gradients over but do not join
+        try:
+            runner.outputs["loss"].backward()
+        finally:
+            ops.DEFER_JOIN = False
         t1 = time.perf_counter() if prof is not None else 0.0
         runner.reducer.finish()
-        runner.arena.sgd_step(runner.active_ranges, runner.lr, runner.momentum, runner.weight_decay,
-                              1.0 / gdist.world_size())
+        scale = 1.0 / gdist.world_size()
+        early, late = runner.split_ranges()
+        ck = ops.SIDE_CHECKPOINT
+        if ck is not None and early:
+            # gradients of everything behind the checkpoint are final once the side stream has passed
+            # it: update those parameters while the stem / stage-1 weight gradients still run
+            torch.cuda.current_stream().wait_event(ck)
+            runner.arena.sgd_step(early, runner.lr, runner.momentum, runner.weight_decay, scale)
+            ops.join_side_streams()
+            runner.arena.sgd_step(late, runner.lr, runner.momentum, runner.weight_decay, scale)
+        else:
+            ops.join_side_streams()
+            runner.arena.sgd_step(runner.active_ranges, runner.lr, runner.momentum,
+                                  runner.weight_decay, scale)
         if prof is not None:
             prof["backward"] = prof.get("backward", 0.0) + (t1 - t0)
             prof["finish+sgd"] = prof.get("finish+sgd", 0.0) + (time.perf_counter() - t1)
@@ -147,6 +165,7 @@ class IterBasedRunner:
         self.active_ranges = None      # merged arena ranges of trainable_params
         self.arch_key = None
         self.arch_meta = None
+        self._split_cache = {}
         # GS_HOST_PROF=1: accumulate host-side seconds per phase of train_iter (diagnostics)
         self.host_prof = {} if os.environ.get("GS_HOST_PROF") else None
         self.set_arch(None)
@@ -182,6 +201,22 @@ class IterBasedRunner:
         self.trainable_params = [p for p in self.active_params if p.requires_grad]
         key = self.arch_key if self.arch_key != ("current",) else None
         self.active_ranges = self.arena.ranges_for(self.trainable_params, key)
+
+    def split_ranges(self):
+        """(early, late) parts of active_ranges: `late` covers the parameters whose weight gradients
+        are produced last in backward (backbone.late_gradient_parameters), `early` the rest."""
+        key = self.arch_key if self.arch_key != ("current",) else None
+        cached = self._split_cache.get(key) if key is not None else None
+        if cached is not None:
+            return cached
+        late_fn = getattr(getattr(self.model, "backbone", None), "late_gradient_parameters", None)
+        late_ids = {id(p) for p in late_fn()} if late_fn is not None else set()
+        early_p = [p for p in self.trainable_params if id(p) not in late_ids]
+        late_p = [p for p in self.trainable_params if id(p) in late_ids]
+        out = (self.arena.ranges_for(early_p), self.arena.ranges_for(late_p))
+        if key is not None:
+            self._split_cache[key] = out
+        return out
 
     def train_iter(self, data_batch):
         prof = self.host_prof

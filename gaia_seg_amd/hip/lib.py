@@ -54,6 +54,17 @@ class SlideDesc(Structure):
                                        "ny", "nx", "align_corners", "flip", "reserved")]
 
 
+class AugmentDesc(Structure):
+    """Mirror of ``gs_augment_desc``."""
+    _fields_ = ([(k, c_int32) for k in ("src_h", "src_w", "src_is_rgb", "res_h", "res_w", "crop_y",
+                                        "crop_x", "crop_h", "crop_w", "out_h", "out_w", "flip",
+                                        "pm_enable", "pm_brightness", "pm_contrast",
+                                        "pm_contrast_first", "pm_saturation", "pm_hue")] +
+                [("pm_delta", c_float), ("pm_alpha", c_float), ("pm_sat_alpha", c_float),
+                 ("pm_hue_delta", c_int32), ("to_rgb", c_int32), ("mean", c_float * 3),
+                 ("std", c_float * 3), ("pad_val", c_float), ("seg_pad_val", c_int32)])
+
+
 _P = c_void_p  # device pointers and the stream travel as plain addresses
 _i32, _i64, _f32, _f64, _sz = c_int32, c_int64, c_float, c_double, c_size_t
 _CD, _CE, _BN = POINTER(ConvDesc), POINTER(CeDesc), POINTER(BnArgs)
@@ -110,6 +121,7 @@ PROTOTYPES = {
     "gs_ce_label_prob": (_i32, [_CE, _P, _P, _P, _P]),
     "gs_resize_argmax": (_i32, [_CE, _P, _P, _P, _P]),
     "gs_slide_fuse": (_i32, [POINTER(SlideDesc), POINTER(_i32), POINTER(_i32), _P, _P, _P, _P, _P]),
+    "gs_seg_augment": (_i32, [POINTER(AugmentDesc), _P, _P, _P, _P, _P]),
     "gs_ohem_workspace_bytes": (_sz, []),
     "gs_ohem_weights": (_i32, [_P, _i64, _i64, _f32, _i32, _P, _P, _sz, _P]),
     "gs_confusion_matrix": (_i32, [_P, _P, _i64, _i32, _i32, _P, _P]),

@@ -37,8 +37,69 @@ def _side_stream(dev):
     return s
 
 
+# Weight gradients are handed to the side stream in BATCHES: every hand-over costs one event on the
+# main stream (hipEventRecord puts a marker packet into the queue; the r02 kernel trace shows a
+# ~7 us bubble behind each of them, 57 per R50 step).  A conv's backward therefore only queues its
+# weight-gradient job; after WGRAD_BATCH jobs (or at the end of a tape, or before a gradient bucket
+# is all-reduced) one event covers them all and the jobs are launched on the side stream.  The
+# "gradient ready" notifications of the reducer fire when the job is actually enqueued.
+WGRAD_BATCH = max(1, int(os.environ.get("GS_WGRAD_BATCH", "4")))
+_wgrad_jobs = []
+
+
+def queue_wgrad(d, x, dy, weight, gw, need, dev):
+    """x: Act (kept alive until the launch), dy: gradient of the conv output, gw: weight.grad."""
+    _wgrad_jobs.append((d, x, dy, weight, gw, need, dev))
+    if len(_wgrad_jobs) >= WGRAD_BATCH:
+        flush_wgrads()
+
+
+def flush_wgrads():
+    """One event for all queued weight-gradient jobs, then launch them on the side stream."""
+    global _wgrad_jobs
+    if not _wgrad_jobs:
+        return
+    jobs, _wgrad_jobs = _wgrad_jobs, []
+    L = _L()
+    dev = jobs[0][6]
+    side = _side_stream(dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.gs_stream_fork(current_stream_ptr(), side.cuda_stream), "gs_stream_fork")
+        for d, x, dy, weight, gw, need, _ in jobs:
+            ws_s = _side_workspace(need, dev, side)
+            dy.record_stream(side)
+            x.t.record_stream(side)
+            _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
+                                         ws_s.data_ptr(), ws_s.numel(), side.cuda_stream),
+                       "gs_conv2d_wgrad")
+    _side_dirty[(dev.type, dev.index)] = True
+    for job in jobs:
+        _notify(job[3])
+
+
+DEFER_JOIN = False   # the runner sets it to overlap the optimizer step with the last weight gradients
+SIDE_CHECKPOINT = None   # event on the side stream: every weight gradient queued before it is done
+
+
+def side_checkpoint(tape):
+    """Mark a point of the backward replay (recorded in forward order, so it fires when backward
+    crosses it): all weight gradients of the layers AFTER this point have been handed to the side
+    stream; an event on the side stream lets the optimizer update those parameters while the side
+    stream still works on the layers before the point (the runner waits on SIDE_CHECKPOINT)."""
+    def backward():
+        global SIDE_CHECKPOINT
+        if not DEFER_JOIN:
+            return
+        flush_wgrads()
+        for key, s in _side_streams.items():
+            if _side_dirty.get(key):
+                SIDE_CHECKPOINT = s.record_event()
+    tape.record(backward)
+
+
 def join_side_streams(dev=None):
     """Make the current stream wait for the weight-gradient kernels queued on the side stream."""
+    flush_wgrads()
     for key, s in _side_streams.items():
         if _side_dirty.get(key) and (dev is None or (dev.type, dev.index) == key):
             with torch.cuda.device(s.device):
@@ -233,19 +294,11 @@ def conv2d(tape, x, weight, bias, co, stride=1, pad=0, dil=1, out=None, tag=None
         if weight.requires_grad:
             gw = ensure_grad(weight)
             if SIDE_WGRAD:
-                side = _side_stream(dev)
-                _lib.check(L.gs_stream_fork(s, side.cuda_stream), "gs_stream_fork")  # dy ready
-                ws_s = _side_workspace(need, dev, side)
-                dy.record_stream(side)
-                x.t.record_stream(side)
-                _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
-                                             ws_s.data_ptr(), ws_s.numel(), side.cuda_stream),
-                           "gs_conv2d_wgrad")
-                _side_dirty[(dev.type, dev.index)] = True
+                queue_wgrad(d, x, dy, weight, gw, need, dev)   # notifies when launched
             else:
                 _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
                                              ws_b.data_ptr(), ws_b.numel(), s), "gs_conv2d_wgrad")
-            _notify(weight)
+                _notify(weight)
         if bias is not None and bias.requires_grad:
             gb = ensure_grad(bias)
             rows = out.rows
@@ -547,26 +600,21 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
                 x.new_grad() if x.parent is None else _alloc_parent_grad(x)
             dx_ptr = x.g.data_ptr()
         ws_b = _ws.get(need, dev)
-        side = _side_stream(dev) if (SIDE_WGRAD and gw is not None) else None
-        if side is not None:
-            ws_s = _side_workspace(need, dev, side)
-            dy.record_stream(side)
-            x.t.record_stream(side)
+        queued = SIDE_WGRAD and gw is not None
         _lib.check(L.gs_conv_bn_backward(
             ctypes.byref(d), x.ptr, weight.data_ptr(), y.ptr, out.ptr, out.ld, coeffs.data_ptr(),
             ctypes.byref(args), dz.data_ptr(), dz.stride(2), mask, 1 if want_g else 0,
             dy.data_ptr(), bsums.data_ptr(), ggamma.data_ptr() if wgrad_bn else None,
-            gbeta.data_ptr() if bgrad_bn else None, gw.data_ptr() if gw is not None else None,
-            dx_ptr, acc, ws_b.data_ptr(), ws_b.numel(),
-            ws_s.data_ptr() if side is not None else None, ws_s.numel() if side is not None else 0,
-            s, side.cuda_stream if side is not None else None), "gs_conv_bn_backward")
-        if side is not None:
-            _side_dirty[(dev.type, dev.index)] = True
+            gbeta.data_ptr() if bgrad_bn else None,
+            gw.data_ptr() if (gw is not None and not queued) else None,
+            dx_ptr, acc, ws_b.data_ptr(), ws_b.numel(), None, 0, s, None), "gs_conv_bn_backward")
         if wgrad_bn:
             _notify(bn.weight)
         if bgrad_bn:
             _notify(bn.bias)
-        if gw is not None:
+        if queued:
+            queue_wgrad(d, x, dy, weight, gw, need, dev)     # the side stream gets it in a batch
+        elif gw is not None:
             _notify(weight)
         if residual is not None and residual.requires_grad:
             src = dz  # masked (relu) or plain (no relu) upstream gradient

@@ -196,7 +196,10 @@ class Tape:
         for fn in reversed(ops):
             fn()
         from . import ops as _ops
-        _ops.join_side_streams()   # weight gradients queued on the side stream
+        if _ops.DEFER_JOIN:
+            _ops.flush_wgrads()        # the caller joins (runner: after the early part of the SGD step)
+        else:
+            _ops.join_side_streams()   # weight gradients queued on the side stream
 
 
 BACKWARD_PROFILE = None

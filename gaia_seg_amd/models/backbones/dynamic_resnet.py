@@ -194,9 +194,20 @@ class DynamicResNet(nn.Module, DynamicMixin):
         outs = []
         for i, layer_name in enumerate(self.res_layers):
             x = getattr(self, layer_name).forward_act(tape, x)
+            if i == 0:
+                # backward crosses this point last-but-one: parameters of every later layer can be
+                # updated while the side stream finishes the stem / stage-1 weight gradients
+                ops.side_checkpoint(tape)
             if i in self.out_indices:
                 outs.append(x)
         return outs
+
+    def late_gradient_parameters(self):
+        """Parameters whose weight gradients are produced after the side-stream checkpoint (the
+        stem and stage 1): the optimizer updates them last."""
+        mods = [self.stem] if self.deep_stem else [self.conv1, self.norm1]
+        mods.append(getattr(self, self.res_layers[0]))
+        return [p for m in mods for p in m.parameters()]
 
     def forward(self, x):
         needs = any(p.requires_grad for p in self.parameters())

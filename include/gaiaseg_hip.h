@@ -414,6 +414,39 @@ int gs_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
                 float momentum, float weight_decay, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Training input pipeline                                             */
+/* ------------------------------------------------------------------------------------------ */
+/* One sample of the reference's train_pipeline (configs/_dynamic_/models/
+ * pspnet_ar50to101v2_gsync.py:60-75: Resize(ratio_range) -> RandomCrop -> RandomFlip ->
+ * PhotoMetricDistortion -> Normalize(to_rgb) -> Pad -> DefaultFormatBundle) as one gather kernel
+ * from the ORIGINAL uint8 image [src_h][src_w][3] and label map [src_h][src_w] on the device to
+ * out_img fp32 [3][out_h][out_w] and out_label int64 [out_h][out_w] (may be NULL).  The random
+ * decisions are made by the caller and passed in the descriptor:
+ *   res_h, res_w      size of the (virtual) resized image        (mmcv.imrescale)
+ *   crop_y/x, crop_h/w the crop window inside it, crop <= out     (RandomCrop; the rest is padding)
+ *   flip              horizontal flip of the crop                 (RandomFlip)
+ *   pm_*              PhotoMetricDistortion: brightness delta, contrast alpha (first = mode 1),
+ *                     saturation alpha, integer hue delta (uint8 HSV, H in [0,180))
+ *   mean/std/to_rgb   Normalize; pad_val / seg_pad_val            (Pad)
+ * Resize: image bilinear with half-pixel centres rounded to uint8, label nearest. */
+typedef struct gs_augment_desc {
+  int32_t src_h, src_w, src_is_rgb;
+  int32_t res_h, res_w;
+  int32_t crop_y, crop_x, crop_h, crop_w;
+  int32_t out_h, out_w;
+  int32_t flip;
+  int32_t pm_enable, pm_brightness, pm_contrast, pm_contrast_first, pm_saturation, pm_hue;
+  float pm_delta, pm_alpha, pm_sat_alpha;
+  int32_t pm_hue_delta;
+  int32_t to_rgb;
+  float mean[3], std[3];
+  float pad_val;
+  int32_t seg_pad_val;
+} gs_augment_desc;
+int gs_seg_augment(const gs_augment_desc* d, const uint8_t* img, const uint8_t* label,
+                   float* out_img, int64_t* out_label, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Tuning hook (tools/sweep_conv_plans.py): force tile rows (64|128), tile columns            */
 /* (32|48|64|80|96|128) and split-K factor of the following gs_conv2d_* calls; bm = 0 restores */
 /* the planner.  Process-global, not thread-safe, results stay exact (only the fixed summation */

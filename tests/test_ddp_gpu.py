@@ -68,10 +68,17 @@ def _norm_checksum(model):
     return s, a
 
 
-def _worker(rank, world, port, head_norm, q, seed_per_rank=False, backbone_norm=None, steps=3):
+def _worker(rank, world, port, head_norm, q, seed_per_rank=False, backbone_norm=None, steps=3,
+            backend="gloo"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":       # RCCL: one GPU per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
     from gaia_seg_amd.core.synthetic import make_batch
     model = _build(head_norm, seed=rank if seed_per_rank else 0, backbone_norm=backbone_norm).cuda().train()
     runner, arena = _runner(model)
@@ -170,3 +177,14 @@ def test_two_rank_syncbn_equals_one_process_on_the_concatenated_batch():
     ns, na = _norm_checksum(model)      # na = total distance the BN affine parameters moved
     assert na > 1e-3
     assert abs(ns - r0[6][0]) <= 1e-3 * na and abs(na - r0[6][1]) <= 1e-3 * na
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+def test_two_ranks_over_rccl_match_the_gloo_run():
+    """The same two-rank training over RCCL (xGMI) as over gloo: identical subnet sequence, ranks in
+    lockstep, and the parameters equal the gloo run's up to the all-reduce's summation order."""
+    n0, n1 = _spawn("SyncBN", backend="nccl")
+    assert n0[3] == n1[3] and n0[1] == n1[1] and n0[2] == n1[2] and n0[5] == n1[5] > 0
+    g0, _ = _spawn("SyncBN")
+    assert n0[3] == g0[3]
+    assert abs(n0[1] - g0[1]) <= 1e-6 * g0[2] and abs(n0[2] - g0[2]) <= 1e-6 * g0[2]

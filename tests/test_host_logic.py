@@ -183,3 +183,50 @@ def test_bn_calibration_switches():
     assert net[0].running_mean is None and net[0].track_running_stats is False
     # eval-mode BN without running statistics normalises with the batch it sees
     assert net[0].eval().bn_params(8).running_mean is None
+
+
+def test_train_pipeline_random_decisions_follow_the_cpu_transforms():
+    """draw_train_params consumes numpy's RandomState in the order mmseg's transforms do
+    (Resize.random_sample_ratio, RandomCrop.get_crop_bbox, RandomFlip, PhotoMetricDistortion)."""
+    import numpy as np
+    from gaia_seg_amd.datasets.gpu_pipeline import draw_train_params, rescale_size
+    assert rescale_size(1024, 2048, (2048, 1024)) == (1024, 2048)
+    assert rescale_size(1024, 2048, (1024, 512)) == (512, 1024)
+    assert rescale_size(300, 500, (int(2048 * 0.7), int(1024 * 0.7))) == (716, 1193)  # short edge binds
+    cfg = dict(crop_size=(512, 1024), img_scale=(2048, 1024), ratio_range=(0.5, 2.0), cat_max_ratio=1.0)
+    rng = np.random.RandomState(0)
+    p = draw_train_params(rng, 1024, 2048, cfg)
+    ref = np.random.RandomState(0)
+    ratio = ref.random_sample() * 1.5 + 0.5
+    rh, rw = rescale_size(1024, 2048, (int(2048 * ratio), int(1024 * ratio)))
+    assert (p["res_h"], p["res_w"]) == (rh, rw)
+    oy = ref.randint(0, max(rh - 512, 0) + 1)
+    ox = ref.randint(0, max(rw - 1024, 0) + 1)
+    assert (p["crop_y"], p["crop_x"]) == (oy, ox)
+    assert p["flip"] == bool(ref.rand() < 0.5)
+    assert p["pm_brightness"] == bool(ref.randint(2))
+    for seed in range(50):          # invariants over many draws
+        p = draw_train_params(np.random.RandomState(seed), 1024, 2048, cfg)
+        assert 512 <= p["res_h"] <= 2048 and p["res_w"] == 2 * p["res_h"]
+        assert p["crop_y"] + p["crop_h"] <= p["res_h"] and p["crop_x"] + p["crop_w"] <= p["res_w"]
+        assert p["crop_h"] == 512 and p["crop_w"] == 1024
+        assert -32 <= p["pm_delta"] <= 32 and 0.5 <= p["pm_alpha"] <= 1.5 and -18 <= p["pm_hue_delta"] < 18
+        assert p["pm_contrast_first"] in (True, False)
+
+
+def test_oracle_pipeline_identity_and_pad():
+    import numpy as np
+    from oracle.pipeline import bgr2hsv, hsv2bgr, train_sample
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, size=(40, 60, 3)).astype(np.uint8)
+    lab = rng.randint(0, 19, size=(40, 60)).astype(np.uint8)
+    p = dict(res_h=40, res_w=60, crop_y=0, crop_x=0, crop_h=40, crop_w=60, flip=False, pm_enable=False)
+    out, ol = train_sample(img, lab, p, crop_size=(48, 64), mean=(0, 0, 0), std=(1, 1, 1), to_rgb=False)
+    assert np.array_equal(out[:, :40, :60], img.transpose(2, 0, 1).astype(np.float32))
+    assert float(np.abs(out[:, 40:]).max()) == 0.0 and int((ol[40:] != 255).sum()) == 0
+    assert np.array_equal(ol[:40, :60], lab)
+    # 8-bit HSV round trip stays within the quantisation of H (2 degrees) and S
+    back = hsv2bgr(bgr2hsv(img.astype(np.float32)))
+    assert float(np.abs(back - img).max()) <= 6
+    grey = np.full((2, 2, 3), 77, np.float32)
+    assert np.array_equal(hsv2bgr(bgr2hsv(grey)), grey)
