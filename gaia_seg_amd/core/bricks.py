@@ -335,7 +335,8 @@ def build_activation_layer(cfg):
     return build_from_cfg(cfg, ACTIVATION_LAYERS)
 
 
-def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=None, defer=False):
+def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=None, defer=False,
+                owns_input_grad=False):
     """conv -> norm (+ residual) (+ ReLU).  ``defer``: leave the BN + ReLU to the consumer's operand
     loaders where the fused path allows it (ops.conv_bn).  Rank-local BatchNorm after a bias-free conv goes through
     the one-call-per-direction library entry (ops.conv_bn); SyncBN with a process group, a conv
@@ -350,7 +351,7 @@ def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=No
             conv._check_layout()
             return ops.conv_bn(tape, x, conv.weight, c, bnp, conv.stride, conv.padding,
                                conv.dilation, relu=relu, residual=residual, out=out, tag=tag,
-                               defer=defer)
+                               defer=defer, owns_input_grad=owns_input_grad)
     y = conv.forward_act(tape, x, tag=tag)
     return norm.forward_act(tape, y, relu=relu, residual=residual, out=out)
 
@@ -506,11 +507,17 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
                                           % [type(m).__name__ for m in self.downsample])
         # bn1 -> conv2 / bn2 -> conv3 (ops.DEFER_EDGES): the normalised activation is never stored;
         # the consumer (forward and weight gradient) evaluates relu(bn(.)) in its operand loaders
+        # owns_input_grad: the conv's data gradient is the last contribution to its input's gradient,
+        # so its epilogue may also do the BatchNorm-backward reduction of the layer that produced
+        # that input (conv2 / conv3 are the only consumers of theirs; conv1's input also feeds the
+        # identity branch, whose gradient is in place before conv1's backward runs — unless a
+        # projection shortcut consumes it too, which runs after conv1 in the reversed replay)
         out = conv_bn_act(tape, self.conv1, self.norm1, x, relu=True,
-                          defer="conv2" in ops.DEFER_EDGES)
+                          defer="conv2" in ops.DEFER_EDGES, owns_input_grad=self.downsample is None)
         out = conv_bn_act(tape, self.conv2, self.norm2, out, relu=True, tag="k3",
-                          defer="conv3" in ops.DEFER_EDGES)
-        return conv_bn_act(tape, self.conv3, self.norm3, out, relu=True, residual=identity)
+                          defer="conv3" in ops.DEFER_EDGES, owns_input_grad=True)
+        return conv_bn_act(tape, self.conv3, self.norm3, out, relu=True, residual=identity,
+                           owns_input_grad=True)
 
     def forward(self, x):
         needs = any(p.requires_grad for p in self.parameters())

@@ -28,6 +28,16 @@ int bn_tile_finalize(const float* part, int np, int bm, long rows, int C, const 
                      const float* beta, float eps, float momentum, float* running_mean,
                      float* running_var, float* coeffs, hipStream_t st);
 
+// norm.hip: out[0..width) = fixed-order sum over nparts partial rows (quad-major layout)
+int bn_sum_partials(const float* part, int nparts, int width, float* out, hipStream_t st);
+
+// igemm_dgrad.hip: data gradient, optionally with the producer BatchNorm's backward reduction folded
+// into the epilogue (gs_bn_bwd_fuse); *fused tells whether that happened
+int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
+                      int accumulate, void* workspace, size_t workspace_bytes, void* stream,
+                      const gs_bn_bwd_fuse* bw, int* fused);
+size_t dgrad_bnbwd_part_bytes(const gs_conv_desc* d);
+
 // fused_layers.hip: live timer of the role-1 (K3) forward launches
 bool k3_prof_on();
 void k3_prof_begin(hipStream_t st);

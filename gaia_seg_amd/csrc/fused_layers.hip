@@ -29,6 +29,8 @@ extern "C" size_t gs_conv_bn_workspace_bytes(const gs_conv_desc* d) {
   size_t m = a > b ? a : b;
   if (fused > m) m = fused;
   if (tiles > m) m = tiles;
+  const size_t bnb = dgrad_bnbwd_part_bytes(d);   // backward: fused BN-backward epilogue partials
+  if (bnb > m) m = bnb;
   return m;
 }
 
@@ -81,18 +83,23 @@ extern "C" int gs_conv_bn_backward(const gs_conv_desc* d, const float* x, const 
                                    float* bsums, float* dgamma, float* dbeta, float* dw, float* dx,
                                    int32_t accumulate_dx, void* workspace, size_t workspace_bytes,
                                    void* side_workspace, size_t side_workspace_bytes, void* stream,
-                                   void* side_stream) {
+                                   void* side_stream, const gs_bn_bwd_fuse* input_bn,
+                                   int32_t sums_ready) {
   if (!d || !bn || !coeffs || !dz || !dy || !bsums) return GS_E_NULL;
+  if (input_bn && input_bn->reserved != 0) return GS_E_BADARG;
   const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
   const int32_t C = d->Co;
-  int rc = gs_bn_bwd_reduce(dz, ld_dz, y, d->ldy, z, ldz, rows, C, coeffs, mask_mode,
-                            write_g ? dz : nullptr, ld_dz, bsums, workspace, workspace_bytes,
-                            stream);
-  if (rc != GS_OK) return rc;
-  // dz already holds the masked gradient when write_g: the apply pass must not mask again
+  int rc = GS_OK;
+  if (!sums_ready) {
+    rc = gs_bn_bwd_reduce(dz, ld_dz, y, d->ldy, z, ldz, rows, C, coeffs, mask_mode,
+                          write_g ? dz : nullptr, ld_dz, bsums, workspace, workspace_bytes, stream);
+    if (rc != GS_OK) return rc;
+  }
+  // dz already holds the masked gradient when write_g (or when a consumer's dgrad epilogue produced
+  // it together with the sums): the apply pass must not mask again
   rc = gs_bn_bwd_apply(dz, ld_dz, y, d->ldy, z, ldz, rows, C, coeffs, bsums, (double)rows,
-                       write_g ? 0 : mask_mode, bn->use_batch_stats, dy, d->ldy, dgamma, dbeta,
-                       stream);
+                       (write_g || sums_ready) ? 0 : mask_mode, bn->use_batch_stats, dy, d->ldy,
+                       dgamma, dbeta, stream);
   if (rc != GS_OK) return rc;
   if (dw) {
     if (side_stream) {
@@ -104,7 +111,13 @@ extern "C" int gs_conv_bn_backward(const gs_conv_desc* d, const float* x, const 
     }
     if (rc != GS_OK) return rc;
   }
-  if (dx) rc = gs_conv2d_dgrad(d, dy, w, dx, accumulate_dx, workspace, workspace_bytes, stream);
+  if (input_bn && input_bn->fused) *input_bn->fused = 0;
+  if (dx) {
+    int fused = 0;
+    rc = conv2d_dgrad_impl(d, dy, w, dx, accumulate_dx, workspace, workspace_bytes, stream, input_bn,
+                           &fused);
+    if (input_bn && input_bn->fused) *input_bn->fused = fused;
+  }
   return rc;
 }
 

@@ -68,6 +68,17 @@ struct IgemmArgs {
   // fly from the producer BatchNorm's coefficients [scale | beta | mean | invstd][Cs] (the
   // normalised activation is never stored; padding stays exactly zero)
   const float* a_coeffs;
+  // dgrad only: the output dX is the gradient of z = relu(bn(y) [+ residual]) of the PRODUCER layer.
+  // bw_mode != 0 folds that BatchNorm's backward reduction into this epilogue: the tile (after the
+  // optional accumulate) is masked with the ReLU mask (mode 1: (y - mean) * scale + beta > 0,
+  // mode 2: bw_act > 0), the masked gradient g is what gets stored, and per-tile sums
+  // {sum g, sum g * xhat} go to bw_part ([2][Nn/4][tiles_m] float4, quad-major) for
+  // sum_partials_kernel — the separate bn_bwd_partial pass over dz and y disappears.
+  const float* bw_y;       // the producer BN's input, pixel stride bw_ldy
+  const float* bw_act;     // mode 2: its post-activation output, pixel stride bw_ldact
+  const float* bw_coeffs;  // [scale | beta | mean | invstd][Nn]
+  float* bw_part;
+  int bw_ldy, bw_ldact, bw_mode;
 };
 
 constexpr int kAffMaxC = 640;   // widest gathered operand of the supernet (stage-4 planes)
@@ -367,6 +378,62 @@ __device__ __forceinline__ void rows_epilogue(
   using T = Tile<BM, BN>;
   float* Cs = lds;
   constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
+  if (p.bw_mode != 0 && !p.slab) {
+    // ---- dgrad + BatchNorm-backward reduction of the producer layer (see IgemmArgs::bw_*) ----
+    // fixed thread -> column-quad map (q = t & 15, rows t >> 4, +16, ...), so a thread keeps its
+    // coefficients and its two partial sums in registers; the 16 threads of a quad are then summed
+    // in a fixed order through LDS (the C image is free by then).
+    static_assert(T::CCH <= 64 && NT == 256, "16 quads x 16 row groups");
+    const int q = t & 15, rg = t >> 4;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (ch > 0) __syncthreads();
+      acc_to_lds<BM, BN>(Cs, acc, ch, wave, lane);
+      __syncthreads();
+      const int col = n0 + ch * T::CCH + q * 4;
+      const bool cv = q * 4 < T::CCH && ch * T::CCH + q * 4 < BN && col < p.Nn;
+      f32x4 s1{0.f, 0.f, 0.f, 0.f}, s2{0.f, 0.f, 0.f, 0.f};
+      if (cv) {
+        const f32x4 scale = *reinterpret_cast<const f32x4*>(p.bw_coeffs + col);
+        const f32x4 beta = *reinterpret_cast<const f32x4*>(p.bw_coeffs + p.Nn + col);
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(p.bw_coeffs + 2 * p.Nn + col);
+        const f32x4 invstd = *reinterpret_cast<const f32x4*>(p.bw_coeffs + 3 * p.Nn + col);
+        for (int row = rg; row < BM; row += 16) {
+          const int m = m0 + row;
+          if (m >= p.M) break;
+          f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * T::PC + q * 4]);
+          const long pix = out_pixel(p, m);
+          float* o = p.out + pix * p.ld_out + col;
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+          const f32x4 yv = *reinterpret_cast<const f32x4*>(p.bw_y + pix * p.bw_ldy + col);
+          f32x4 key;
+          if (p.bw_mode == 2) key = *reinterpret_cast<const f32x4*>(p.bw_act + pix * p.bw_ldact + col);
+          else key = (yv - mean) * scale + beta;          // the expression of bn_apply / masked_grad
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = key[e] > 0.f ? v[e] : 0.f;
+          *reinterpret_cast<f32x4*>(o) = v;
+          s1 += v;
+          s2 += v * ((yv - mean) * invstd);
+        }
+      }
+      __syncthreads();                       // every thread is done with the C image
+      f32x4* red = reinterpret_cast<f32x4*>(Cs);   // [2][16 row groups][16 quads]
+      red[rg * 16 + q] = s1;
+      red[256 + rg * 16 + q] = s2;
+      __syncthreads();
+      if (rg == 0 && cv) {
+        for (int g = 1; g < 16; ++g) {
+          s1 += red[g * 16 + q];
+          s2 += red[256 + g * 16 + q];
+        }
+        const long C4 = p.Nn >> 2, np = p.tiles_m, tm = m0 / BM;
+        f32x4* part4 = reinterpret_cast<f32x4*>(p.bw_part);
+        part4[(0 * C4 + (col >> 2)) * np + tm] = s1;
+        part4[(1 * C4 + (col >> 2)) * np + tm] = s2;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     if (ch > 0) __syncthreads();

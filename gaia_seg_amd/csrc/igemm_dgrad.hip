@@ -1,5 +1,6 @@
 // DynConv2d data gradient (implicit GEMM, fp32 MFMA) — see igemm_core.h
 #include "igemm_core.h"
+#include "fused_internal.h"
 
 using namespace gs;
 
@@ -101,6 +102,23 @@ static int dgrad_strided_fast(const gs_conv_desc* d, const float* dy, const floa
 extern "C" int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
                                int accumulate, void* workspace, size_t workspace_bytes,
                                void* stream) {
+  return conv2d_dgrad_impl(d, dy, w, dx, accumulate, workspace, workspace_bytes, stream, nullptr,
+                           nullptr);
+}
+
+namespace gs {
+// per-tile partial sums of the fused BatchNorm-backward epilogue: [2][Ci/4][tiles_m] float4
+size_t dgrad_bnbwd_part_bytes(const gs_conv_desc* d) {
+  if (check_desc(d) != GS_OK || d->stride != 1 || (d->Ci & 3)) return 0;
+  const Plan pl = plan_dgrad(d);
+  if (pl.splits != 1) return 0;
+  return (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
+}
+
+int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
+                      int accumulate, void* workspace, size_t workspace_bytes, void* stream,
+                      const gs_bn_bwd_fuse* bw, int* fused) {
+  if (fused) *fused = 0;
   int rc = check_desc(d);
   if (rc != GS_OK) return rc;
   if (!dy || !w || !dx) return GS_E_NULL;
@@ -142,6 +160,20 @@ extern "C" int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const flo
   a.src_bytes = (unsigned)src_b;
   a.dense_bytes = (unsigned)dense_b;
   const bool fast = fast_rows_ok(d->Co, ks, src_b, dense_b) && getenv("GS_NO_FAST") == nullptr;
+  static const bool no_bnb = getenv("GS_NO_BNBWD_FUSE") != nullptr;
+  bool bnb = false;
+  if (bw && !no_bnb && d->stride == 1 && fast && pl.splits == 1 && bw->y && bw->coeffs && bw->sums &&
+      (bw->mode == 1 || (bw->mode == 2 && bw->act))) {
+    const size_t part_b = (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
+    if (workspace && part_b <= workspace_bytes && aligned16(workspace) && aligned16(bw->y) &&
+        aligned16(bw->coeffs) && (bw->ldy & 3) == 0 && bw->ldy >= d->Ci &&
+        (bw->mode == 1 || (aligned16(bw->act) && (bw->ldact & 3) == 0 && bw->ldact >= d->Ci))) {
+      a.bw_y = bw->y; a.bw_ldy = bw->ldy; a.bw_act = bw->act; a.bw_ldact = bw->ldact;
+      a.bw_coeffs = bw->coeffs; a.bw_mode = bw->mode;
+      a.bw_part = static_cast<float*>(workspace);
+      bnb = true;
+    }
+  }
   if (d->stride == 1) {
     if (fast && ks == 1) launch_rows_fast<true, 1>(pl, a, st);
     else if (fast && ks == 3) launch_rows_fast<true, 3>(pl, a, st);
@@ -159,6 +191,11 @@ extern "C" int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const flo
     launch_reduce(a, pl.splits, 0, st);
     rc = launch_status();
   }
+  if (bnb && rc == GS_OK) {
+    rc = bn_sum_partials(a.bw_part, pl.tiles_m, 2 * d->Ci, bw->sums, st);
+    if (fused) *fused = 1;
+  }
   return rc;
 }
+}  // namespace gs
 

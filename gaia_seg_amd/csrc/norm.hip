@@ -607,6 +607,10 @@ int bn_reduce_stats_finalize(const float* slab, int splits, long rows, int C, fl
                      (double)rows, gamma, beta, eps, momentum, running_mean, running_var, coeffs);
   return launch_status();
 }
+int bn_sum_partials(const float* part, int nparts, int width, float* out, hipStream_t st) {
+  launch_sum_partials(part, nparts, width, out, nullptr, 0, st);
+  return launch_status();
+}
 // coeffs from the per-tile partials the conv epilogue wrote
 int bn_tile_finalize(const float* part, int np, int bm, long rows, int C, const float* gamma,
                      const float* beta, float eps, float momentum, float* running_mean,

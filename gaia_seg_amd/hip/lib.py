@@ -16,7 +16,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgaiaseg_hip.so")
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HipLibraryError(RuntimeError):
@@ -38,6 +38,13 @@ class BnArgs(Structure):
     _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p),
                 ("running_var", c_void_p), ("eps", c_float), ("momentum", c_float),
                 ("use_batch_stats", c_int32), ("update_running", c_int32), ("relu", c_int32),
+                ("reserved", c_int32)]
+
+
+class BnBwdFuse(Structure):
+    """Mirror of ``gs_bn_bwd_fuse``."""
+    _fields_ = [("y", c_void_p), ("act", c_void_p), ("coeffs", c_void_p), ("sums", c_void_p),
+                ("fused", POINTER(c_int32)), ("ldy", c_int32), ("ldact", c_int32), ("mode", c_int32),
                 ("reserved", c_int32)]
 
 
@@ -133,7 +140,8 @@ PROTOTYPES = {
     "gs_conv_bn_workspace_bytes": (_sz, [_CD]),
     "gs_conv_bn_forward": (_i32, [_CD, _P, _P, _BN, _P, _i32, _P, _P, _P, _i32, _P, _sz, _P]),
     "gs_conv_bn_backward": (_i32, [_CD, _P, _P, _P, _P, _i32, _P, _BN, _P, _i32, _i32, _i32, _P, _P,
-                                   _P, _P, _P, _P, _i32, _P, _sz, _P, _sz, _P, _P]),
+                                   _P, _P, _P, _P, _i32, _P, _sz, _P, _sz, _P, _P, POINTER(BnBwdFuse),
+                                   _i32]),
     "gs_k3_timer_enable": (_i32, [_i32]),
     "gs_k3_timer_read": (_i32, [POINTER(_i64), POINTER(_f64), POINTER(_f64)]),
 }

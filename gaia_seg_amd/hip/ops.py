@@ -509,8 +509,12 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
     return out
 
 
+BNBWD_FUSE = os.environ.get("GS_NO_BNBWD_FUSE") is None
+BNBWD_FUSED_COUNT = 0   # diagnostics: how many BN-backward reductions ran inside a dgrad epilogue
+
+
 def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
-            tag=None, defer=False):
+            tag=None, defer=False, owns_input_grad=False):
     """z = act(BN(conv(x, weight[:co, :x.C])) (+ residual)) through ONE library call per direction
     (gs_conv_bn_forward / gs_conv_bn_backward): same kernels, same results as conv2d() followed by
     batchnorm(), a third of the host work.  Rank-local BatchNorm only (``bn.process_group`` None);
@@ -519,7 +523,12 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
     ``defer`` (with relu, no residual, no ``out``): the BN + ReLU is NOT applied here; the returned
     activation carries the coefficients (Act.affine) and its consumer — the next conv_bn — evaluates
     relu(bn(y)) in its operand loaders, forward and weight gradient (gs_conv_desc.in_affine).  A
-    deferred INPUT ``x`` is consumed that way when the library supports the shape, else written out."""
+    deferred INPUT ``x`` is consumed that way when the library supports the shape, else written out.
+
+    ``owns_input_grad``: this conv's data gradient is the LAST contribution to ``x.g`` (accumulation
+    included).  If x came out of a training-mode BN + ReLU (``x.bnb``), the dgrad epilogue then also
+    applies that ReLU's mask and reduces that BN's backward sums (gs_bn_bwd_fuse): the producer's
+    backward finds them in ``x.bnb_sums`` and skips its reduction pass over dz and y."""
     L = _L()
     co_eff = round_up(co, 4)
     dev = x.t.device
@@ -577,6 +586,9 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
         _trace_relu_deferred(bn, y, coeffs)
     elif relu:
         _trace_relu(bn, out)
+    if relu and use_batch and BNBWD_FUSE and tape.enabled and out.parent is None:
+        out.bnb = (y, coeffs, 2 if residual is not None else 1, out if residual is not None else None)
+    x_bnb = x.bnb if (owns_input_grad and BNBWD_FUSE and x.requires_grad) else None
 
     def backward():
         dz = out.g
@@ -584,6 +596,7 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
             return
         s = current_stream_ptr()
         mask = 0 if not relu else (2 if residual is not None else 1)
+        sums_ready = out.bnb_sums is not None    # a consumer's dgrad epilogue did the reduction
         want_g = residual is not None and residual.requires_grad and relu
         wgrad_bn = bn.weight is not None and bn.weight.requires_grad
         bgrad_bn = bn.bias is not None and bn.bias.requires_grad
@@ -591,7 +604,7 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
         gbeta = ensure_grad(bn.bias) if bgrad_bn else None
         gw = ensure_grad(weight) if weight.requires_grad else None
         dy = torch.empty_like(y.t)
-        bsums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        bsums = out.bnb_sums if sums_ready else torch.empty(2 * C, dtype=torch.float32, device=dev)
         acc = 0
         dx_ptr = None
         if x.requires_grad:
@@ -599,6 +612,17 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
             if not acc:
                 x.new_grad() if x.parent is None else _alloc_parent_grad(x)
             dx_ptr = x.g.data_ptr()
+        fuse, fused_flag, in_sums = None, None, None
+        if x_bnb is not None and dx_ptr is not None and x.parent is None:
+            py, pcoeffs, pmode, pact = x_bnb
+            in_sums = torch.empty(2 * x.C, dtype=torch.float32, device=dev)
+            fused_flag = ctypes.c_int32(0)
+            fuse = _lib.BnBwdFuse()
+            fuse.y, fuse.ldy = py.ptr, py.ld
+            fuse.act, fuse.ldact = (pact.ptr, pact.ld) if pact is not None else (None, 0)
+            fuse.coeffs, fuse.sums = pcoeffs.data_ptr(), in_sums.data_ptr()
+            fuse.fused = ctypes.pointer(fused_flag)
+            fuse.mode, fuse.reserved = pmode, 0
         ws_b = _ws.get(need, dev)
         queued = SIDE_WGRAD and gw is not None
         _lib.check(L.gs_conv_bn_backward(
@@ -607,7 +631,13 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
             dy.data_ptr(), bsums.data_ptr(), ggamma.data_ptr() if wgrad_bn else None,
             gbeta.data_ptr() if bgrad_bn else None,
             gw.data_ptr() if (gw is not None and not queued) else None,
-            dx_ptr, acc, ws_b.data_ptr(), ws_b.numel(), None, 0, s, None), "gs_conv_bn_backward")
+            dx_ptr, acc, ws_b.data_ptr(), ws_b.numel(), None, 0, s, None,
+            ctypes.byref(fuse) if fuse is not None else None, 1 if sums_ready else 0),
+            "gs_conv_bn_backward")
+        if fuse is not None and fused_flag.value:
+            global BNBWD_FUSED_COUNT
+            BNBWD_FUSED_COUNT += 1
+            x.bnb_sums = in_sums     # x.g now holds the MASKED gradient of the producer's ReLU
         if wgrad_bn:
             _notify(bn.weight)
         if bgrad_bn:

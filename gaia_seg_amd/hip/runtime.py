@@ -74,7 +74,7 @@ class Act:
     ``nchw_image`` marks the network input, which is read in place through NCHW strides."""
 
     __slots__ = ("t", "_g", "requires_grad", "parent", "c0", "nchw_image",
-                 "N", "H", "W", "C", "ld", "rows", "ptr", "affine")
+                 "N", "H", "W", "C", "ld", "rows", "ptr", "affine", "bnb", "bnb_sums")
 
     def __init__(self, t, requires_grad=True, parent=None, c0=0, nchw_image=False):
         self.t = t
@@ -88,6 +88,12 @@ class Act:
         # consumer convolution applies it in its operand loader (gs_conv_desc.in_affine) or
         # ops.materialize() writes it out.  ``g`` is always the gradient of the logical value.
         self.affine = None
+        # Cross-layer fusion of the BatchNorm backward reduction (ops.conv_bn): ``bnb`` = (y Act,
+        # coefficient tensor, mask mode, post-activation Act or None) describes the BN + ReLU that
+        # produced this activation; a consumer whose data gradient is the last contribution to ``g``
+        # may fold that BN's reduction into its dgrad epilogue and leaves the sums in ``bnb_sums``.
+        self.bnb = None
+        self.bnb_sums = None
         # geometry, fixed for the life of the object (t is never rebound): plain attributes, these
         # are read several times per kernel launch
         shp = t.shape

@@ -214,14 +214,33 @@ int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const float* w, co
  * post-activation tensor for mode 2).  dy: scratch [N*Ho*Wo][ldy] receiving the gradient of the conv
  * output; bsums: scratch [2*Co].  dgamma/dbeta/dw/dx may be NULL (not needed).  side_stream != NULL
  * runs the weight gradient there (forked after dy is complete; the caller joins it later with
- * gs_stream_fork(side_stream, stream)) using side_workspace. */
+ * gs_stream_fork(side_stream, stream)) using side_workspace.
+ *
+ * Cross-layer fusion of the BatchNorm backward reduction (the bn_bwd_partial pass over dz and y):
+ *   input_bn != NULL: x is the output of relu(bn_prev(y_prev) [+ residual]) and this call's data
+ *     gradient is the LAST contribution to its gradient (accumulate_dx included).  Where the dgrad
+ *     kernel allows it (stride 1, no split-K, fast path) its epilogue masks the gradient with that
+ *     ReLU's mask, stores the masked gradient g into dx and reduces {sum g, sum g * xhat_prev} into
+ *     input_bn->sums; *input_bn->fused is set to 1 (else 0 and dx holds the plain gradient).
+ *   sums_ready != 0: THIS layer's dz already is the masked gradient and bsums already holds its
+ *     sums (a consumer's call did the above): the reduction pass is skipped, mask_mode is ignored. */
+typedef struct gs_bn_bwd_fuse {
+  const float* y;        /* bn_prev's input [rows][ldy]                                         */
+  const float* act;      /* mode 2: bn_prev's post-activation output [rows][ldact], else NULL   */
+  const float* coeffs;   /* bn_prev's coefficient block [scale | beta | mean | invstd][Ci]      */
+  float* sums;           /* out: [2*Ci] = {sum g, sum g * xhat}                                  */
+  int32_t* fused;        /* out (host): 1 if the fused epilogue ran                             */
+  int32_t ldy, ldact;
+  int32_t mode;          /* 1: mask = bn_prev(y) > 0 ; 2: mask = act > 0                        */
+  int32_t reserved;
+} gs_bn_bwd_fuse;
 int gs_conv_bn_backward(const gs_conv_desc* d, const float* x, const float* w, const float* y,
                         const float* z, int32_t ldz, const float* coeffs, const gs_bn_args* bn,
                         float* dz, int32_t ld_dz, int32_t mask_mode, int32_t write_g, float* dy,
                         float* bsums, float* dgamma, float* dbeta, float* dw, float* dx,
                         int32_t accumulate_dx, void* workspace, size_t workspace_bytes,
                         void* side_workspace, size_t side_workspace_bytes, void* stream,
-                        void* side_stream);
+                        void* side_stream, const gs_bn_bwd_fuse* input_bn, int32_t sums_ready);
 
 /* Live timer of the gs_conv2d_forward launches with role GS_CONV_ROLE_BOTTLENECK3X3 (HIP events on
  * the launch stream around the conv kernel and its split-K reduce): bench.py's `roofline`.

@@ -567,3 +567,47 @@ def test_deferred_bn_relu_in_operand_loaders(hip_lib, case, monkeypatch):
     assert rel_err(dx, xr.grad) < 3e-4
     for got, ref in zip((g_ca, g_baw, g_bab, g_cb, g_bbw, g_bbb), pr):
         assert rel_err(got, ref.grad) < 3e-4
+
+
+# BatchNorm-backward reduction folded into the consumer's dgrad epilogue (gs_bn_bwd_fuse): a stage of
+# two bottlenecks (the second without projection shortcut, so conv1's dgrad accumulates onto the
+# identity gradient and owns its input's gradient) must give the same gradients with and without the
+# fusion, and the fusion must actually have run (mode 1 for bn1 / bn2, mode 2 for bn3).
+@pytest.mark.parametrize("shape", [(2, 64, 96, 16), (1, 40, 72, 48)])
+def test_bn_backward_reduction_in_dgrad_epilogue(hip_lib, shape, monkeypatch):
+    import gaia_seg_amd.hip.ops as ops
+    from gaia_seg_amd.core.bricks import DynamicBottleneck
+    from gaia_seg_amd.models.utils import DynamicResLayer
+    n, h, w, planes = shape
+    torch.manual_seed(2)
+    layer = DynamicResLayer(DynamicBottleneck, 32, planes, depth=3, stride=1,
+                            conv_cfg=dict(type="DynConv2d"), norm_cfg=dict(type="DynBN"))
+    for m in layer.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+            torch.nn.init.normal_(m.bias, 0, 0.2)
+        elif hasattr(m, "weight") and getattr(m, "weight", None) is not None and m.weight.dim() == 4:
+            torch.nn.init.normal_(m.weight, 0, (2.0 / (m.weight.shape[1] * m.weight.shape[2] ** 2)) ** 0.5)
+    layer = layer.to(DEV).train()
+    x = torch.randn(n, 32, h, w)
+    gz = torch.randn(n, 4 * planes, h, w)
+    results, counts = [], []
+    for fuse in (True, False):
+        monkeypatch.setattr(ops, "BNBWD_FUSE", fuse)
+        ops.BNBWD_FUSED_COUNT = 0
+        for p in layer.parameters():
+            p.grad = None
+        for m in layer.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.zero_()
+                m.running_var.fill_(1)
+        xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        z = layer(xg)
+        z.backward(gz.to(DEV).contiguous(memory_format=torch.channels_last))
+        counts.append(ops.BNBWD_FUSED_COUNT)
+        results.append([z.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
+    # block 0: bn1 (conv2 owns), bn2 (conv3 owns); blocks 1, 2: + bn3 of the block before (conv1 owns)
+    assert counts[0] == 2 + 3 + 3 and counts[1] == 0
+    assert torch.equal(results[0][0], results[1][0])
+    for a, b in zip(results[0][1:], results[1][1:]):
+        assert rel_err(a, b) < 2e-5
