@@ -61,6 +61,8 @@ class ParamArena:
             self.segments[id(p)] = (o, round_up(max(n, 1), _ALIGN))
             self.names[id(p)] = name
         self._range_cache = {}
+        # True while every gradient element is zero outside a running step (see zero_grad)
+        self.grads_clean = False
 
     @staticmethod
     def _view(flat, p, phys, off, n):
@@ -91,20 +93,26 @@ class ParamArena:
         return merged
 
     def zero_grad(self, ranges=None):
+        """Clear gradients.  A no-op while ``grads_clean`` holds: the buffer starts at zero and every
+        sgd_step(zero_grad=True) clears what the step wrote, so a training loop that always follows
+        backward with such a step over the same ranges never needs the fill kernels."""
+        if self.grads_clean:
+            return
         if ranges is None:
             self.flat_grad.zero_()
         else:
             for a, b in ranges:
                 self.flat_grad[a:b].zero_()
 
-    def sgd_step(self, ranges, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
+    def sgd_step(self, ranges, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, zero_grad=False):
         """torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov=False) on the ranges."""
         L = _lib.load()
         st = current_stream_ptr()
         pb, gb, mb = self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.flat_mom.data_ptr()
         for a, b in ranges:
             _lib.check(L.gs_sgd_step(pb + 4 * a, gb + 4 * a, mb + 4 * a, b - a, lr, momentum,
-                                     weight_decay, grad_scale, st), "gs_sgd_step")
+                                     weight_decay, grad_scale, 1 if zero_grad else 0, st),
+                       "gs_sgd_step")
 
     def momentum_views(self):
         """{parameter name: momentum buffer as a LOGICAL (OIHW / plain) view of the flat arena}."""

@@ -99,13 +99,15 @@ class ArenaOptimizerHook(Hook):
             # gradients of everything behind the checkpoint are final once the side stream has passed
             # it: update those parameters while the stem / stage-1 weight gradients still run
             torch.cuda.current_stream().wait_event(ck)
-            runner.arena.sgd_step(early, runner.lr, runner.momentum, runner.weight_decay, scale)
+            runner.arena.sgd_step(early, runner.lr, runner.momentum, runner.weight_decay, scale, True)
             ops.join_side_streams()
-            runner.arena.sgd_step(late, runner.lr, runner.momentum, runner.weight_decay, scale)
+            runner.arena.sgd_step(late, runner.lr, runner.momentum, runner.weight_decay, scale, True)
         else:
             ops.join_side_streams()
             runner.arena.sgd_step(runner.active_ranges, runner.lr, runner.momentum,
-                                  runner.weight_decay, scale)
+                                  runner.weight_decay, scale, True)
+        # the step cleared exactly the ranges backward wrote: the next zero_grad has nothing to do
+        runner.arena.grads_clean = True
         if prof is not None:
             prof["backward"] = prof.get("backward", 0.0) + (t1 - t0)
             prof["finish+sgd"] = prof.get("finish+sgd", 0.0) + (time.perf_counter() - t1)
@@ -225,7 +227,8 @@ class IterBasedRunner:
             self.model.train()
         self.call_hook("before_train_iter")
         t1 = time.perf_counter() if prof is not None else 0.0
-        self.arena.zero_grad(self.active_ranges)
+        self.arena.zero_grad(self.active_ranges)   # (a no-op after a clearing optimizer step)
+        self.arena.grads_clean = False             # backward is about to write gradients
         self.reducer.begin(self.trainable_params,
                            self.arch_key if self.arch_key != ("current",) else None)
         t2 = time.perf_counter() if prof is not None else 0.0

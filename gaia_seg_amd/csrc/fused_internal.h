@@ -31,6 +31,11 @@ int bn_tile_finalize(const float* part, int np, int bm, long rows, int C, const 
 // norm.hip: out[0..width) = fixed-order sum over nparts partial rows (quad-major layout)
 int bn_sum_partials(const float* part, int nparts, int width, float* out, hipStream_t st);
 
+size_t bn_reduce_bnbwd_bytes(long rows, int C);
+int bn_reduce_bnbwd(const float* slab, int splits, long rows, int C, float* dx, int ld_dx,
+                    int accumulate, const gs_bn_bwd_fuse* bw, float* part, size_t part_bytes,
+                    hipStream_t st);
+
 // igemm_dgrad.hip: data gradient, optionally with the producer BatchNorm's backward reduction folded
 // into the epilogue (gs_bn_bwd_fuse); *fused tells whether that happened
 int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, float* dx,

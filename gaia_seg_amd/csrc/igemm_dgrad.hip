@@ -108,10 +108,14 @@ extern "C" int gs_conv2d_dgrad(const gs_conv_desc* d, const float* dy, const flo
 
 namespace gs {
 // per-tile partial sums of the fused BatchNorm-backward epilogue: [2][Ci/4][tiles_m] float4
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// workspace of the fused path: per-tile partials (no split-K), or the slabs followed by the row-block
+// partials of the fused slab reduce
 size_t dgrad_bnbwd_part_bytes(const gs_conv_desc* d) {
   if (check_desc(d) != GS_OK || d->stride != 1 || (d->Ci & 3)) return 0;
   const Plan pl = plan_dgrad(d);
-  if (pl.splits != 1) return 0;
+  const long M = (long)d->N * d->H * d->W;
+  if (pl.splits != 1) return align256(slab_bytes(pl, M, d->Ci)) + bn_reduce_bnbwd_bytes(M, d->Ci);
   return (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
 }
 
@@ -161,17 +165,21 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
   a.dense_bytes = (unsigned)dense_b;
   const bool fast = fast_rows_ok(d->Co, ks, src_b, dense_b) && getenv("GS_NO_FAST") == nullptr;
   static const bool no_bnb = getenv("GS_NO_BNBWD_FUSE") != nullptr;
-  bool bnb = false;
-  if (bw && !no_bnb && d->stride == 1 && fast && pl.splits == 1 && bw->y && bw->coeffs && bw->sums &&
-      (bw->mode == 1 || (bw->mode == 2 && bw->act))) {
-    const size_t part_b = (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
-    if (workspace && part_b <= workspace_bytes && aligned16(workspace) && aligned16(bw->y) &&
-        aligned16(bw->coeffs) && (bw->ldy & 3) == 0 && bw->ldy >= d->Ci &&
-        (bw->mode == 1 || (aligned16(bw->act) && (bw->ldact & 3) == 0 && bw->ldact >= d->Ci))) {
-      a.bw_y = bw->y; a.bw_ldy = bw->ldy; a.bw_act = bw->act; a.bw_ldact = bw->ldact;
-      a.bw_coeffs = bw->coeffs; a.bw_mode = bw->mode;
-      a.bw_part = static_cast<float*>(workspace);
-      bnb = true;
+  bool bnb = false, bnb_split = false;
+  if (bw && !no_bnb && d->stride == 1 && fast && bw->y && bw->coeffs && bw->sums &&
+      (bw->mode == 1 || (bw->mode == 2 && bw->act)) && workspace && aligned16(workspace) &&
+      aligned16(bw->y) && aligned16(bw->coeffs) && (bw->ldy & 3) == 0 && bw->ldy >= d->Ci &&
+      (bw->mode == 1 || (aligned16(bw->act) && (bw->ldact & 3) == 0 && bw->ldact >= d->Ci))) {
+    if (pl.splits == 1) {
+      const size_t part_b = (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
+      if (part_b <= workspace_bytes) {
+        a.bw_y = bw->y; a.bw_ldy = bw->ldy; a.bw_act = bw->act; a.bw_ldact = bw->ldact;
+        a.bw_coeffs = bw->coeffs; a.bw_mode = bw->mode;
+        a.bw_part = static_cast<float*>(workspace);
+        bnb = true;
+      }
+    } else if (align256(need) + bn_reduce_bnbwd_bytes(M, d->Ci) <= workspace_bytes) {
+      bnb_split = true;   // the slab reduce does the masking and the sums
     }
   }
   if (d->stride == 1) {
@@ -187,6 +195,14 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
   }
   rc = launch_status();
   if (rc != GS_OK) return rc;
+  if (bnb_split) {
+    const size_t off = align256(need);
+    rc = bn_reduce_bnbwd(a.slab, pl.splits, M, d->Ci, dx, (int)d->x_sw, accumulate ? 1 : 0, bw,
+                         reinterpret_cast<float*>(static_cast<char*>(workspace) + off),
+                         workspace_bytes - off, st);
+    if (rc == GS_OK && fused) *fused = 1;
+    return rc;
+  }
   if (pl.splits > 1) {
     launch_reduce(a, pl.splits, 0, st);
     rc = launch_status();

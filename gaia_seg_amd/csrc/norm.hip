@@ -502,6 +502,50 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(
 }
 
 
+// (c) data gradient with split-K whose output is the gradient of z = relu(bn_prev(y) [+ residual]):
+//     fixed-order sum of the slabs (+ the gradient already accumulated in dx), the producer's ReLU
+//     mask, the store of the masked gradient g and that BatchNorm's backward sums {sum g, sum g xhat}
+//     in one pass — the split-K form of the fused dgrad epilogue (igemm_core.h rows_epilogue, bw_*).
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_reduce_bnbwd_kernel(
+    const float* __restrict__ slab, int splits, long rows, int C, float* dx, int ld_dx, int accumulate,
+    const float* __restrict__ yprev, int ldy, const float* __restrict__ act, int ldact,
+    const float* __restrict__ coeffs, long rows_per_block, float* __restrict__ part) {
+  __shared__ f32x4 sh[512];
+  const int C4 = C >> 2;
+  const ColMap m = col_map(C4);
+  f32x4 s1{0.f, 0.f, 0.f, 0.f}, s2{0.f, 0.f, 0.f, 0.f};
+  if (m.active) {
+    const f32x4 scale = *reinterpret_cast<const f32x4*>(coeffs + m.cq * 4);
+    const f32x4 beta = *reinterpret_cast<const f32x4*>(coeffs + C + m.cq * 4);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(coeffs + 2 * C + m.cq * 4);
+    const f32x4 invstd = *reinterpret_cast<const f32x4*>(coeffs + 3 * C + m.cq * 4);
+    const long zs = rows * C;   // slab stride
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(r0 + rows_per_block, rows);
+    for (long r = r0 + m.rr; r < r1; r += m.rpi) {
+      const float* sp = slab + r * C + m.cq * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+      for (int z = 1; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(sp + z * zs);
+      float* o = dx + r * ld_dx + m.cq * 4;
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(yprev + r * ldy + m.cq * 4);
+      f32x4 av{0.f, 0.f, 0.f, 0.f};
+      if (MODE == 2) av = *reinterpret_cast<const f32x4*>(act + r * ldact + m.cq * 4);
+      v = masked_grad<MODE>(v, yv, av, mean, scale, beta);
+      *reinterpret_cast<f32x4*>(o) = v;
+      s1 += v;
+      s2 += v * ((yv - mean) * invstd);
+    }
+  }
+  block_reduce_rows(s1, s2, m, C4, sh);
+  if (m.active && m.rr == 0) {
+    f32x4* part4 = reinterpret_cast<f32x4*>(part);
+    part4[(long)m.cq * gridDim.x + blockIdx.x] = s1;
+    part4[((long)C4 + m.cq) * gridDim.x + blockIdx.x] = s2;
+  }
+}
+
 // ---------------- SyncBN exchange helpers (one launch each instead of ~25 tiny tensor ops) -------
 // local[0..C) = mean, local[C..2C) = biased variance, local[2C] = count  (double), from the shifted
 // sums {S1, S2, shift} of gs_bn_stats: the payload a rank contributes to the all_gather.
@@ -605,6 +649,27 @@ int bn_reduce_stats_finalize(const float* slab, int splits, long rows, int C, fl
   if (timed) k3_prof_end(st, flops);   // the K3 interval covers the conv and its slab reduction
   hipLaunchKernelGGL(bn_sum_finalize_kernel, dim3(C / 4), dim3(256), 0, st, part, g.gx, C, y,
                      (double)rows, gamma, beta, eps, momentum, running_mean, running_var, coeffs);
+  return launch_status();
+}
+size_t bn_reduce_bnbwd_bytes(long rows, int C) {
+  const RedGeom g = red_geom(rows, C);
+  return (size_t)g.gx * 2 * C * sizeof(float);
+}
+// dx = mask(sum of slabs [+ dx]); sums = {sum g, sum g * xhat_prev}  (see splitk_reduce_bnbwd_kernel)
+int bn_reduce_bnbwd(const float* slab, int splits, long rows, int C, float* dx, int ld_dx,
+                    int accumulate, const gs_bn_bwd_fuse* bw, float* part, size_t part_bytes,
+                    hipStream_t st) {
+  const RedGeom g = red_geom(rows, C);
+  if ((size_t)g.gx * 2 * C * sizeof(float) > part_bytes) return GS_E_WORKSPACE;
+  if (bw->mode == 2)
+    hipLaunchKernelGGL(splitk_reduce_bnbwd_kernel<2>, dim3(g.gx, g.gy), dim3(256), 0, st, slab, splits,
+                       rows, C, dx, ld_dx, accumulate, bw->y, bw->ldy, bw->act, bw->ldact, bw->coeffs,
+                       g.rows_per_block, part);
+  else
+    hipLaunchKernelGGL(splitk_reduce_bnbwd_kernel<1>, dim3(g.gx, g.gy), dim3(256), 0, st, slab, splits,
+                       rows, C, dx, ld_dx, accumulate, bw->y, bw->ldy, bw->act, bw->ldact, bw->coeffs,
+                       g.rows_per_block, part);
+  launch_sum_partials(part, g.gx, 2 * C, bw->sums, nullptr, 0, st);
   return launch_status();
 }
 int bn_sum_partials(const float* part, int nparts, int width, float* out, hipStream_t st) {

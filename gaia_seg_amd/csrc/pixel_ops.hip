@@ -344,7 +344,10 @@ __global__ __launch_bounds__(256) void scale_nc_kernel(const float* x, int ldx,
 }
 
 // torch.optim.SGD step over a flat range (cfg: pspnet_ar50to101v2_gsync.py:175)
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+// ZERO: the gradient is cleared once it has been consumed (the next step then needs no zero_grad
+// fill kernels in front of its forward pass)
+template <bool ZERO>
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g,
                                                   float* __restrict__ m, long n4, float lr,
                                                   float momentum, float wd, float gscale) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     f32x4 mv = reinterpret_cast<f32x4*>(m)[i] * momentum + gv;
     reinterpret_cast<f32x4*>(m)[i] = mv;
     reinterpret_cast<f32x4*>(p)[i] = pv - mv * lr;
+    if (ZERO) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 
@@ -654,15 +658,20 @@ extern "C" int gs_scale_nc(const float* x, int32_t ldx, const float* mask, int32
   return launch_status();
 }
 
-extern "C" int gs_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
-                           float lr, float momentum, float weight_decay, float grad_scale,
+extern "C" int gs_sgd_step(float* param, float* grad, float* momentum_buf, int64_t n, float lr,
+                           float momentum, float weight_decay, float grad_scale, int32_t zero_grad,
                            void* stream) {
   if (!param || !grad || !momentum_buf) return GS_E_NULL;
   if (n <= 0) return GS_E_BADARG;
   if ((n & 3) || !aligned16(param) || !aligned16(grad) || !aligned16(momentum_buf))
     return GS_E_ALIGN;
-  hipLaunchKernelGGL(sgd_kernel, dim3(stream_grid(n >> 2, 256)), dim3(256), 0, as_stream(stream),
-                     param, grad, momentum_buf, (long)(n >> 2), lr, momentum, weight_decay,
-                     grad_scale);
+  if (zero_grad)
+    hipLaunchKernelGGL(sgd_kernel<true>, dim3(stream_grid(n >> 2, 256)), dim3(256), 0,
+                       as_stream(stream), param, grad, momentum_buf, (long)(n >> 2), lr, momentum,
+                       weight_decay, grad_scale);
+  else
+    hipLaunchKernelGGL(sgd_kernel<false>, dim3(stream_grid(n >> 2, 256)), dim3(256), 0,
+                       as_stream(stream), param, grad, momentum_buf, (long)(n >> 2), lr, momentum,
+                       weight_decay, grad_scale);
   return launch_status();
 }

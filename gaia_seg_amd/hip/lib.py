@@ -132,7 +132,7 @@ PROTOTYPES = {
     "gs_ohem_workspace_bytes": (_sz, []),
     "gs_ohem_weights": (_i32, [_P, _i64, _i64, _f32, _i32, _P, _P, _sz, _P]),
     "gs_confusion_matrix": (_i32, [_P, _P, _i64, _i32, _i32, _P, _P]),
-    "gs_sgd_step": (_i32, [_P, _P, _P, _i64, _f32, _f32, _f32, _f32, _P]),
+    "gs_sgd_step": (_i32, [_P, _P, _P, _i64, _f32, _f32, _f32, _f32, _i32, _P]),
     "gs_debug_force_plan": (_i32, [_i32, _i32, _i32]),
     "gs_debug_query_plan": (_i32, [_i32, _i32, _i32, _i32, POINTER(_i32), POINTER(_i32), POINTER(_i32),
                                    POINTER(_i32)]),

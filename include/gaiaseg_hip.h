@@ -428,9 +428,11 @@ int gs_confusion_matrix(const int64_t* pred, const int64_t* label, int64_t n, in
  * into a few ranges (parameters of depth-skipped blocks are not in any range: no update at all).
  * momentum_buf starts at zero, so the first use gives buf = g exactly as torch does.
  *   g = grad*grad_scale + weight_decay*p ; buf = momentum*buf + g ; p -= lr*buf
- * grad_scale is 1/world_size for the data-parallel mean. n % 4 == 0, pointers 16-byte aligned. */
-int gs_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
-                float momentum, float weight_decay, float grad_scale, void* stream);
+ * grad_scale is 1/world_size for the data-parallel mean. n % 4 == 0, pointers 16-byte aligned.
+ * zero_grad != 0 clears grad after use (optimizer.zero_grad() of the NEXT iteration folded in:
+ * OptimizerHook's zero_grad -> backward -> step order). */
+int gs_sgd_step(float* param, float* grad, float* momentum_buf, int64_t n, float lr,
+                float momentum, float weight_decay, float grad_scale, int32_t zero_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Training input pipeline                                             */

@@ -61,7 +61,7 @@ def test_argument_validation_needs_no_gpu():
     d = lib.ConvDesc()
     assert L.gs_conv2d_workspace_bytes(ctypes.byref(d)) == 0
     assert L.gs_conv2d_forward(ctypes.byref(d), None, None, None, None, None, None, 0, None) == -1
-    assert L.gs_sgd_step(None, None, None, 16, 0.1, 0.9, 0.0, 1.0, None) == -4
+    assert L.gs_sgd_step(None, None, None, 16, 0.1, 0.9, 0.0, 1.0, 0, None) == -4
     with pytest.raises(lib.HipLibraryError):
         lib.check(-3, "probe")
 
