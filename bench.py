@@ -79,8 +79,9 @@ def host_cores():
 
 def k3_traffic():
     """HBM bytes per K3 launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
-    rocprofv3 --pmc runs of this script; see profiles/r01_k3_traffic.json).  Counters cannot be
-    read from inside the process, so this is the committed measurement, or None."""
+    rocprofv3 --pmc runs of this script on the sampled mix; tools/pmc_summary.py hbm ->
+    profiles/rNN_k3_traffic.json).  Counters cannot be read from inside the process, so this is the
+    latest committed measurement, or None."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k3_traffic.json")), reverse=True):
         try:

@@ -4,11 +4,14 @@
     python tools/pmc_summary.py mfma  <csv with SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES> out.md
     python tools/pmc_summary.py hbm   <csv with FETCH_SIZE> <csv with WRITE_SIZE> out.json
 
-mfma: busy fraction of the MFMA pipe per kernel group = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES
-      (both summed over the launches of the group; MI355X_MICROARCH.md: MFMA_BUSY counts cycles).
+mfma: busy fraction of the MFMA pipes per kernel group.  SQ_VALU_MFMA_BUSY_CYCLES is summed over the
+      1024 SIMDs (32 cycles per v_mfma_f32_16x16x4_f32: checked, busy / 32 x 2048 FLOP = the padded FLOPs
+      of the launch); SQ_BUSY_CYCLES is summed over the 32 shader engines (checked: = 32 x duration x
+      clock).  Utilisation = MFMA_BUSY / (1024 x kernel cycles) = (MFMA_BUSY / SQ_BUSY_CYCLES) / 32.
 hbm : bytes per launch of the headline kernel (role-1 bottleneck conv2 forward + its split-K reduce);
       FETCH_SIZE x2 on gfx950 for 16-B/lane reads, WRITE_SIZE exact, both in KiB (HBM section)."""
 import csv
+import gzip
 import json
 import os
 import sys
@@ -18,9 +21,13 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from summarize_rocprof import group  # noqa: E402
 
 
+def _open(path):
+    return gzip.open(path, "rt") if path.endswith(".gz") else open(path)
+
+
 def read(path):
     per = defaultdict(dict)   # dispatch -> {counter: value, name}
-    for r in csv.DictReader(open(path)):
+    for r in csv.DictReader(_open(path)):
         d = per[r["Dispatch_Id"]]
         d["name"] = r["Kernel_Name"]
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
@@ -39,13 +46,17 @@ def mfma(path, out):
         g[k][2] += d["SQ_BUSY_CYCLES"]
     lines = ["# MFMA pipe busy per kernel group (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES)", "",
              "source: `%s`" % path, "",
-             "busy = sum SQ_VALU_MFMA_BUSY_CYCLES / sum SQ_BUSY_CYCLES over the group's launches "
-             "(SQ_BUSY_CYCLES is summed over the shader engines that ran the kernel; the ratio is the "
-             "fraction of kernel-resident time the MFMA pipe was executing).", "",
-             "| group | launches | MFMA busy |", "|---|---|---|"]
+             "MFMA busy = (sum SQ_VALU_MFMA_BUSY_CYCLES / sum SQ_BUSY_CYCLES) / 32 over the group's "
+             "launches: MFMA_BUSY is summed over the 1024 SIMDs (32 cycles per fp32 16x16x4 MFMA), "
+             "SQ_BUSY_CYCLES over the 32 shader engines, so the quotient / 32 is the fraction of the "
+             "kernel's cycles in which a SIMD's MFMA pipe was executing, averaged over all SIMDs.  "
+             "Counter collection serialises the kernels (no stream overlap).  It includes MFMA work on "
+             "tile padding; `useful GF / launch` = MFMA_BUSY / 32 x 2048 FLOP.", "",
+             "| group | launches | MFMA busy | MFMA GFLOP issued / launch |", "|---|---|---|---|"]
     for k, (n, m, b) in sorted(g.items(), key=lambda kv: -kv[1][1]):
         if m > 0:
-            lines.append("| %s | %d | %.3f |" % (k, n, m / b if b else 0.0))
+            lines.append("| %s | %d | %.3f | %.2f |" % (k, n, m / b / 32.0 if b else 0.0,
+                                                       m / n / 32.0 * 2048 / 1e9))
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 

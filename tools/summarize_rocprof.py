@@ -47,6 +47,8 @@ def group(name):
         return "batchnorm / reductions"
     if re.search(r"ce_|resize_argmax", name):
         return "fused resize + cross entropy"
+    if re.search(r"slide_fuse|seg_augment", name):
+        return "inference epilogue / input pipeline"
     if re.search(r"maxpool|avgpool|bilinear|copy2d|scale_nc", name):
         return "pool / resize / copy"
     if "sgd_kernel" in name:
