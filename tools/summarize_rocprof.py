@@ -39,8 +39,8 @@ def group(name):
     if "igemm_wgrad" in name:                # general kernel <BM, BN, SCALAR, KS>
         ks = name.split("<")[1].split(">")[0].split(", ")[-1]
         return "conv wgrad %s" % {"1": "1x1", "3": "3x3"}.get(ks, "stem/other")
-    if "splitk_reduce_kernel<false, 1>" in name:
-        return K3_RED
+    if "splitk_reduce_kernel<false, 1>" in name or "splitk_reduce_stats_kernel<1>" in name:
+        return K3_RED      # (the fused reduce + BN statistics pass when the K3 timer is off)
     if "splitk_reduce" in name:
         return "split-K reduce"
     if re.search(r"bn_|sum_partials|colsum", name):
