@@ -376,19 +376,18 @@ __global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
   }
 }
 
-// ---- in-launch fan-in (CDNA guide, "in-launch split-K reduction", counter form, sc1 variant) -----
+// ---- in-launch fan-in (CDNA guide, "in-launch split-K reduction", counter form) -----------------
 // Every workgroup of a group calls ticket_last() after its records are stored; it returns true in the
 // workgroup that arrives last, which may then read all records of the group with plain loads.
-// The RECORDS are stored write-through (sc1: store_record), so the writer needs no release fence —
-// an agent-scope release would write back the whole L2, i.e. all the output tiles of the launch, in
-// every workgroup (measured: -11 % images/s); every storing wave drains its stores, barrier, one
-// relaxed agent-scope ticket.  Reader side: ONE agent-scope acquire after drawing the last ticket,
-// barrier.  The counter is reset by the last arriver (the buffer starts zeroed and every launch
-// leaves it so).
+// Writer side: every wave drains its stores, barrier, ONE agent-scope release, drain, relaxed
+// agent-scope ticket; reader side: ONE agent-scope acquire after drawing the last ticket, barrier.
+// The counter is reset by the last arriver (the buffer starts zeroed and every launch leaves it so).
 __device__ __forceinline__ bool ticket_last(unsigned* ctr, unsigned total, float* lds_word) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = t + 1 == total;
     if (last) {
@@ -400,13 +399,6 @@ __device__ __forceinline__ bool ticket_last(unsigned* ctr, unsigned total, float
   }
   __syncthreads();
   return *reinterpret_cast<volatile int*>(lds_word) != 0;
-}
-
-// 16-byte write-through store of a fan-in record (aux 16 = sc1 on gfx950)
-__device__ __forceinline__ void store_record(float* base, long quad_index, f32x4 v) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFF0, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                         rs, (unsigned)(quad_index * 16), 0, 16);
 }
 
 // dst[(which, quad)] = sum over `count` consecutive float4 records src[((which * C4 + quad) * stride
@@ -435,7 +427,7 @@ __device__ __forceinline__ void fanin_sum(const float* __restrict__ src, int C4,
     if (sub == 0) {
       const f32x4 o{(float)a0, (float)a1, (float)a2, (float)a3};
       if (dst_stride == 0) *reinterpret_cast<f32x4*>(dst + (long)which * 4 * C4 + cq * 4) = o;
-      else store_record(dst, ((long)which * C4 + cq) * dst_stride + dpos, o);   // read by another WG
+      else reinterpret_cast<f32x4*>(dst)[((long)which * C4 + cq) * dst_stride + dpos] = o;
     }
   }
 }
@@ -497,14 +489,9 @@ __device__ __forceinline__ void rows_epilogue(
           s2 += red[256 + g * 16 + q];
         }
         const long C4 = p.Nn >> 2, np = p.tiles_m, tm = m0 / BM;
-        if (p.bw_cnt) {   // records of the in-launch fan-in: write-through
-          store_record(p.bw_part, (0 * C4 + (col >> 2)) * np + tm, s1);
-          store_record(p.bw_part, (1 * C4 + (col >> 2)) * np + tm, s2);
-        } else {
-          f32x4* part4 = reinterpret_cast<f32x4*>(p.bw_part);
-          part4[(0 * C4 + (col >> 2)) * np + tm] = s1;
-          part4[(1 * C4 + (col >> 2)) * np + tm] = s2;
-        }
+        f32x4* part4 = reinterpret_cast<f32x4*>(p.bw_part);
+        part4[(0 * C4 + (col >> 2)) * np + tm] = s1;
+        part4[(1 * C4 + (col >> 2)) * np + tm] = s2;
       }
     }
     if (p.bw_cnt) {
