@@ -86,6 +86,7 @@ extern "C" int gs_conv_bn_backward(const gs_conv_desc* d, const float* x, const 
                                    void* side_stream, const gs_bn_bwd_fuse* input_bn,
                                    int32_t sums_ready) {
   if (!d || !bn || !coeffs || !dz || !dy || !bsums) return GS_E_NULL;
+  if (input_bn && input_bn->reserved != 0) return GS_E_BADARG;
   const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
   const int32_t C = d->Co;
   int rc = GS_OK;

@@ -79,12 +79,6 @@ struct IgemmArgs {
   const float* bw_coeffs;  // [scale | beta | mean | invstd][Nn]
   float* bw_part;
   int bw_ldy, bw_ldact, bw_mode;
-  // in-launch fan-in of the per-tile sums (NULL: a separate sum_partials launch does it):
-  // bw_cnt = zeroed, self-resetting tickets [tiles_n][ngroups + 1], bw_grp = group partials
-  // [2][Nn/4][ngroups] float4, bw_sums = the final {sum g, sum g * xhat}[2 * Nn]
-  unsigned* bw_cnt;
-  float* bw_grp;
-  float* bw_sums;
 };
 
 constexpr int kAffMaxC = 640;   // widest gathered operand of the supernet (stage-4 planes)
@@ -376,62 +370,6 @@ __global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
   }
 }
 
-// ---- in-launch fan-in (CDNA guide, "in-launch split-K reduction", counter form) -----------------
-// Every workgroup of a group calls ticket_last() after its records are stored; it returns true in the
-// workgroup that arrives last, which may then read all records of the group with plain loads.
-// Writer side: every wave drains its stores, barrier, ONE agent-scope release, drain, relaxed
-// agent-scope ticket; reader side: ONE agent-scope acquire after drawing the last ticket, barrier.
-// The counter is reset by the last arriver (the buffer starts zeroed and every launch leaves it so).
-__device__ __forceinline__ bool ticket_last(unsigned* ctr, unsigned total, float* lds_word) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = t + 1 == total;
-    if (last) {
-      __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    *reinterpret_cast<volatile int*>(lds_word) = last ? 1 : 0;
-  }
-  __syncthreads();
-  return *reinterpret_cast<volatile int*>(lds_word) != 0;
-}
-
-// dst[(which, quad)] = sum over `count` consecutive float4 records src[((which * C4 + quad) * stride
-// + first + i)] for the quads [q0, q1) and which in {0, 1}; fixed order (4 lanes per pair, each its
-// records in order, then a fixed butterfly), double accumulation.  dst_stride == 0: final sums,
-// written as float4 at dst[which * 4 * C4 + quad * 4]; else record layout with that stride at dpos.
-__device__ __forceinline__ void fanin_sum(const float* __restrict__ src, int C4, int stride, int first,
-                                          int count, int q0, int q1, float* __restrict__ dst,
-                                          int dst_stride, int dpos) {
-  const int t = threadIdx.x, sub = t & 3;
-  const int nq = q1 - q0;
-  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-  for (int pair = t >> 2; pair < 2 * nq; pair += NT / 4) {   // (whole quads of lanes take a pair)
-    const int which = pair / nq, cq = q0 + pair - which * nq;
-    const f32x4* rec = s4 + ((long)which * C4 + cq) * stride + first;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int i = sub; i < count; i += 4) {
-      const f32x4 v = rec[i];
-      a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
-    }
-#pragma unroll
-    for (int off = 1; off <= 2; off <<= 1) {
-      a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64);
-      a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
-    }
-    if (sub == 0) {
-      const f32x4 o{(float)a0, (float)a1, (float)a2, (float)a3};
-      if (dst_stride == 0) *reinterpret_cast<f32x4*>(dst + (long)which * 4 * C4 + cq * 4) = o;
-      else reinterpret_cast<f32x4*>(dst)[((long)which * C4 + cq) * dst_stride + dpos] = o;
-    }
-  }
-}
-
 // Shared epilogue of the row kernels: accumulators -> LDS -> coalesced float4 rows.
 template <int BM, int BN>
 __device__ __forceinline__ void rows_epilogue(
@@ -492,20 +430,6 @@ __device__ __forceinline__ void rows_epilogue(
         f32x4* part4 = reinterpret_cast<f32x4*>(p.bw_part);
         part4[(0 * C4 + (col >> 2)) * np + tm] = s1;
         part4[(1 * C4 + (col >> 2)) * np + tm] = s2;
-      }
-    }
-    if (p.bw_cnt) {
-      // two-level fan-in of the tile sums of this column block: groups of 32 tiles, then the groups
-      // (<= 16 KB of records per merge; only the last group's merges are exposed)
-      const int C4 = p.Nn >> 2, np = p.tiles_m, ng = (np + 31) >> 5;
-      const int tm = m0 / BM, g1 = tm >> 5, tn = n0 / BN;
-      const int q0 = n0 >> 2, q1 = min(n0 + BN, p.Nn) >> 2;
-      unsigned* cnt = p.bw_cnt + (long)tn * (ng + 1);
-      __syncthreads();   // the LDS flag word aliases the reduction scratch
-      if (ticket_last(cnt + g1, (unsigned)min(32, np - g1 * 32), lds)) {
-        fanin_sum(p.bw_part, C4, np, g1 * 32, min(32, np - g1 * 32), q0, q1, p.bw_grp, ng, g1);
-        if (ticket_last(cnt + ng, (unsigned)ng, lds))
-          fanin_sum(p.bw_grp, C4, ng, 0, ng, q0, q1, p.bw_sums, 0, 0);
       }
     }
     return;

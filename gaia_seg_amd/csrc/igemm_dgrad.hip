@@ -116,8 +116,7 @@ size_t dgrad_bnbwd_part_bytes(const gs_conv_desc* d) {
   const Plan pl = plan_dgrad(d);
   const long M = (long)d->N * d->H * d->W;
   if (pl.splits != 1) return align256(slab_bytes(pl, M, d->Ci)) + bn_reduce_bnbwd_bytes(M, d->Ci);
-  // per-tile partials + the group partials of the in-launch fan-in
-  return (size_t)2 * d->Ci * (pl.tiles_m + (pl.tiles_m + 31) / 32) * sizeof(float);
+  return (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
 }
 
 int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
@@ -172,21 +171,12 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
       aligned16(bw->y) && aligned16(bw->coeffs) && (bw->ldy & 3) == 0 && bw->ldy >= d->Ci &&
       (bw->mode == 1 || (aligned16(bw->act) && (bw->ldact & 3) == 0 && bw->ldact >= d->Ci))) {
     if (pl.splits == 1) {
-      const int ng = (pl.tiles_m + 31) / 32;
       const size_t part_b = (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
-      const size_t grp_b = (size_t)2 * d->Ci * ng * sizeof(float);
       if (part_b <= workspace_bytes) {
         a.bw_y = bw->y; a.bw_ldy = bw->ldy; a.bw_act = bw->act; a.bw_ldact = bw->ldact;
         a.bw_coeffs = bw->coeffs; a.bw_mode = bw->mode;
         a.bw_part = static_cast<float*>(workspace);
         bnb = true;
-        static const bool no_tickets = getenv("GS_NO_TICKETS") != nullptr;
-        if (bw->tickets && !no_tickets && (long)pl.tiles_n * (ng + 1) <= bw->n_tickets &&
-            part_b + grp_b <= workspace_bytes && aligned16(bw->sums)) {
-          a.bw_cnt = bw->tickets;
-          a.bw_grp = a.bw_part + (size_t)2 * d->Ci * pl.tiles_m;
-          a.bw_sums = bw->sums;
-        }
       }
     } else if (align256(need) + bn_reduce_bnbwd_bytes(M, d->Ci) <= workspace_bytes) {
       bnb_split = true;   // the slab reduce does the masking and the sums
@@ -218,7 +208,7 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
     rc = launch_status();
   }
   if (bnb && rc == GS_OK) {
-    if (!a.bw_cnt) rc = bn_sum_partials(a.bw_part, pl.tiles_m, 2 * d->Ci, bw->sums, st);
+    rc = bn_sum_partials(a.bw_part, pl.tiles_m, 2 * d->Ci, bw->sums, st);
     if (fused) *fused = 1;
   }
   return rc;

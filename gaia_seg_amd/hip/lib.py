@@ -16,7 +16,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgaiaseg_hip.so")
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 5
+ABI_VERSION = 4
 
 
 class HipLibraryError(RuntimeError):
@@ -44,8 +44,8 @@ class BnArgs(Structure):
 class BnBwdFuse(Structure):
     """Mirror of ``gs_bn_bwd_fuse``."""
     _fields_ = [("y", c_void_p), ("act", c_void_p), ("coeffs", c_void_p), ("sums", c_void_p),
-                ("fused", POINTER(c_int32)), ("tickets", c_void_p), ("ldy", c_int32),
-                ("ldact", c_int32), ("mode", c_int32), ("n_tickets", c_int32)]
+                ("fused", POINTER(c_int32)), ("ldy", c_int32), ("ldact", c_int32), ("mode", c_int32),
+                ("reserved", c_int32)]
 
 
 class CeDesc(Structure):

@@ -511,17 +511,6 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
 
 BNBWD_FUSE = os.environ.get("GS_NO_BNBWD_FUSE") is None
 BNBWD_FUSED_COUNT = 0   # diagnostics: how many BN-backward reductions ran inside a dgrad epilogue
-_tickets = {}            # per device: zeroed, self-resetting ticket words of the in-launch fan-in
-N_TICKETS = 8192
-
-
-def _ticket_buffer(dev):
-    key = (dev.type, dev.index)
-    t = _tickets.get(key)
-    if t is None:
-        t = torch.zeros(N_TICKETS, dtype=torch.int32, device=dev)
-        _tickets[key] = t
-    return t
 
 
 def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
@@ -633,9 +622,7 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
             fuse.act, fuse.ldact = (pact.ptr, pact.ld) if pact is not None else (None, 0)
             fuse.coeffs, fuse.sums = pcoeffs.data_ptr(), in_sums.data_ptr()
             fuse.fused = ctypes.pointer(fused_flag)
-            fuse.mode = pmode
-            tk = _ticket_buffer(dev)     # (dgrads run on the main stream only: one buffer per device)
-            fuse.tickets, fuse.n_tickets = tk.data_ptr(), tk.numel()
+            fuse.mode, fuse.reserved = pmode, 0
         ws_b = _ws.get(need, dev)
         queued = SIDE_WGRAD and gw is not None
         _lib.check(L.gs_conv_bn_backward(

@@ -230,13 +230,9 @@ typedef struct gs_bn_bwd_fuse {
   const float* coeffs;   /* bn_prev's coefficient block [scale | beta | mean | invstd][Ci]      */
   float* sums;           /* out: [2*Ci] = {sum g, sum g * xhat}                                  */
   int32_t* fused;        /* out (host): 1 if the fused epilogue ran                             */
-  uint32_t* tickets;     /* optional device buffer of n_tickets words, ZERO on entry and left   */
-                         /* zero: lets the dgrad kernel sum its per-tile partials itself        */
-                         /* (two-level fan-in by last-arriving workgroups) instead of a         */
-                         /* separate launch; must not be shared by concurrently running calls   */
   int32_t ldy, ldact;
   int32_t mode;          /* 1: mask = bn_prev(y) > 0 ; 2: mask = act > 0                        */
-  int32_t n_tickets;
+  int32_t reserved;
 } gs_bn_bwd_fuse;
 int gs_conv_bn_backward(const gs_conv_desc* d, const float* x, const float* w, const float* y,
                         const float* z, int32_t ldz, const float* coeffs, const gs_bn_args* bn,
