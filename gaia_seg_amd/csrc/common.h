@@ -2,6 +2,7 @@
 // (MI355X only: 64-lane waves, 256 CUs in 8 XCDs; no other target is supported.)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include "gaiaseg_hip.h"
 
@@ -49,6 +50,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
+}
+// Wave-level sum on the VALU's data-parallel-primitive lanes (no LDS traffic, unlike the
+// ds_bpermute behind __shfl_down): an inclusive scan inside each row of 16 lanes, then the two
+// row broadcasts; lane 63 holds the total, returned as a wave-uniform value.  The association order
+// differs from wave_sum's (both are fixed, so results stay run-to-run reproducible).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto shr = [](float x, auto ctrl, auto rows) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x),
+                                                                 decltype(ctrl)::value,
+                                                                 decltype(rows)::value, 0xf, true));
+  };
+  using std::integral_constant;
+  v += shr(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});   // row_shr:1
+  v += shr(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});   // row_shr:2
+  v += shr(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});   // row_shr:4
+  v += shr(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});   // row_shr:8
+  v += shr(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});   // row_bcast:15
+  v += shr(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});   // row_bcast:31
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

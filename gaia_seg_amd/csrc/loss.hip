@@ -205,11 +205,15 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const CeArgs a, const float
 // sums of its four adjacent tiles in a fixed order (bit-reproducible, no atomics).  Power-of-two
 // scales keep the fp32 source coordinates exact, so the tile membership is exact too.
 constexpr int TCH = 20;   // classes per pass (19 Cityscapes classes + pad)
+// blockDim.x = 64, 128 or 256: about four pixels of the tile per thread (gs_ce_backward_tiled), so
+// that the 4 * TCH wave reductions at the end are amortised over enough softmax terms.
 __global__ __launch_bounds__(256) void ce_bwd_tile_kernel(
     const CeArgs a, const float* __restrict__ logits, const int64_t* __restrict__ labels,
     const float* __restrict__ pw, const float* __restrict__ cw, const float* __restrict__ lse,
     float gscale, int sy, int sx, float* __restrict__ part, int cp) {
   __shared__ float sh[4][4 * TCH];
+  __shared__ float4 corner[TCH];   // per class: logits of the tile's four low-resolution pixels
+  const int nthr = blockDim.x, nwave = nthr >> 6;
   const int tw = a.d.w + 1, th = a.d.h + 1;
   const int tx = blockIdx.x % tw;
   const int r = blockIdx.x / tw;
@@ -220,12 +224,25 @@ __global__ __launch_bounds__(256) void ce_bwd_tile_kernel(
   const int nx = x1 - x0, npx = (y1 - y0) * nx;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* prow = part + (long)blockIdx.x * 4 * cp;
+  // every pixel of the tile interpolates between the same (clamped) low-resolution rows / columns
+  const Lerp uy = lerp_coord(min(y0, a.d.H - 1), a.sh, a.d.h, 0);
+  const Lerp ux = lerp_coord(min(x0, a.d.W - 1), a.sw, a.d.w, 0);
+  const float* ub = logits + (long)n * a.d.l_sn;
+  const float* q00 = ub + uy.i0 * a.d.l_sh + ux.i0 * a.d.l_sw;
+  const float* q01 = ub + uy.i0 * a.d.l_sh + ux.i1 * a.d.l_sw;
+  const float* q10 = ub + uy.i1 * a.d.l_sh + ux.i0 * a.d.l_sw;
+  const float* q11 = ub + uy.i1 * a.d.l_sh + ux.i1 * a.d.l_sw;
   for (int c0 = 0; c0 < a.d.Cls; c0 += TCH) {
     const int nc = min(TCH, a.d.Cls - c0);
+    if (threadIdx.x < TCH) {   // classes past nc repeat the last one; their sums are not written
+      const long off = (long)(c0 + min((int)threadIdx.x, nc - 1)) * a.d.l_sc;
+      corner[threadIdx.x] = make_float4(q00[off], q01[off], q10[off], q11[off]);
+    }
+    __syncthreads();
     float a00[TCH], a01[TCH], a10[TCH], a11[TCH];   // corner (row slot, column slot) sums
 #pragma unroll
     for (int c = 0; c < TCH; ++c) { a00[c] = 0.f; a01[c] = 0.f; a10[c] = 0.f; a11[c] = 0.f; }
-    for (int q = threadIdx.x; q < npx; q += 256) {
+    for (int q = threadIdx.x; q < npx; q += nthr) {
       const int Y = y0 + q / nx, X = x0 + q % nx;
       const long pi = ((long)n * a.d.H + Y) * a.d.W + X;
       const long lab = labels[pi];
@@ -244,38 +261,34 @@ __global__ __launch_bounds__(256) void ce_bwd_tile_kernel(
       const float w00 = wy0 * wx0 * coef, w01 = wy0 * wx1 * coef, w10 = wy1 * wx0 * coef,
                   w11 = wy1 * wx1 * coef;
       const float l = lse[pi];
-      const float* b = logits + (long)n * a.d.l_sn;
-      Taps t;
-      t.p00 = b + ly.i0 * a.d.l_sh + lx.i0 * a.d.l_sw;
-      t.p01 = b + ly.i0 * a.d.l_sh + lx.i1 * a.d.l_sw;
-      t.p10 = b + ly.i1 * a.d.l_sh + lx.i0 * a.d.l_sw;
-      t.p11 = b + ly.i1 * a.d.l_sh + lx.i1 * a.d.l_sw;
-      t.w00 = lx.l0; t.w01 = lx.l1; t.w10 = ly.l0; t.w11 = ly.l1;
+      const int labc = (int)lab - c0;
 #pragma unroll
       for (int c = 0; c < TCH; ++c) {
-        if (c < nc) {
-          const float z = tap_value(t, (long)(c0 + c) * a.d.l_sc);
-          float p = expf(z - l);
-          if (c0 + c == lab) p -= 1.f;
-          a00[c] += w00 * p; a01[c] += w01 * p; a10[c] += w10 * p; a11[c] += w11 * p;
-        }
+        const float4 L = corner[c];
+        // tap_value()'s association order, so that exp(z - lse) sums to one as in the forward
+        const float z = ly.l0 * (lx.l0 * L.x + lx.l1 * L.y) + ly.l1 * (lx.l0 * L.z + lx.l1 * L.w);
+        float p = expf(z - l);
+        if (c == labc) p -= 1.f;
+        a00[c] += w00 * p; a01[c] += w01 * p; a10[c] += w10 * p; a11[c] += w11 * p;
       }
     }
 #pragma unroll
     for (int c = 0; c < TCH; ++c) {
-      const float v0 = wave_sum(a00[c]), v1 = wave_sum(a01[c]), v2 = wave_sum(a10[c]),
-                  v3 = wave_sum(a11[c]);
+      const float v0 = wave_sum_dpp(a00[c]), v1 = wave_sum_dpp(a01[c]), v2 = wave_sum_dpp(a10[c]),
+                  v3 = wave_sum_dpp(a11[c]);
       if (lane == 0) {
         sh[wave][c] = v0; sh[wave][TCH + c] = v1; sh[wave][2 * TCH + c] = v2;
         sh[wave][3 * TCH + c] = v3;
       }
     }
     __syncthreads();
-    if (threadIdx.x < 4 * TCH) {
-      const int slot = threadIdx.x / TCH, c = threadIdx.x - slot * TCH;
-      if (c < nc)
-        prow[slot * cp + c0 + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] +
-                                   sh[3][threadIdx.x];
+    for (int i = threadIdx.x; i < 4 * TCH; i += nthr) {
+      const int slot = i / TCH, c = i - slot * TCH;
+      if (c < nc) {
+        float v = sh[0][i];
+        for (int w = 1; w < nwave; ++w) v += sh[w][i];
+        prow[slot * cp + c0 + c] = v;
+      }
     }
     __syncthreads();
   }
@@ -423,7 +436,9 @@ extern "C" int gs_ce_backward_ws(const gs_ce_desc* d, const float* logits, const
   hipStream_t st = as_stream(stream);
   float* part = static_cast<float*>(workspace);
   const int tiles = d->N * (d->h + 1) * (d->w + 1);
-  hipLaunchKernelGGL(ce_bwd_tile_kernel, dim3(tiles), dim3(256), 0, st, a, logits, labels,
+  const int tile_px = sy * sx;
+  const int threads = tile_px >= 1024 ? 256 : tile_px >= 512 ? 128 : 64;
+  hipLaunchKernelGGL(ce_bwd_tile_kernel, dim3(tiles), dim3(threads), 0, st, a, logits, labels,
                      pixel_weight, class_weight, lse, grad_scale, sy, sx, part, ld_d);
   const long total = (long)d->N * d->h * d->w * ld_d;
   hipLaunchKernelGGL(ce_bwd_gather_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, part,

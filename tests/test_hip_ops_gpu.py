@@ -287,7 +287,8 @@ def _ce_ref(logits, label, size, ignore=255, weight=None, cw=None, lw=1.0, align
 
 @pytest.mark.parametrize("shape", [((2, 19, 16, 32), (64, 128)), ((2, 19, 5, 7), (33, 41)),
                                    ((1, 19, 25, 25), (97, 97)), ((2, 150, 4, 4), (16, 16)),
-                                   ((1, 19, 8, 8), (8, 8))])
+                                   ((1, 19, 8, 8), (8, 8)), ((2, 19, 4, 8), (64, 128)),
+                                   ((1, 19, 3, 2), (96, 64)), ((1, 45, 2, 3), (16, 24))])
 def test_fused_resize_ce_fwd_bwd(hip_lib, shape):
     from gaia_seg_amd.hip.runtime import Act
     from gaia_seg_amd.models.losses import seg_loss_and_accuracy
