@@ -128,6 +128,47 @@ struct Tile {
   static constexpr int BV = (BK * BN / 4 + NT - 1) / NT;  // dense float4 per thread
 };
 
+// Which output columns the wave's TN 16-column MFMA blocks own.  The B fragment of block j is one
+// float per lane (lane l = its column inside the block); were block j the columns [16j, 16j+16)
+// every k-group would cost TN ds_read_b32.  Instead the blocks are grouped (fours, then a pair, then
+// a single) and a group of V blocks owns V*16 consecutive columns INTERLEAVED: block j of the group
+// takes columns base + V*l + (j - first), so one ds_read_b128 / b64 per lane fetches the fragments
+// of all V blocks, and the epilogue writes V consecutive accumulator columns with one vector store.
+template <int TN>
+struct ColGroups {
+  static constexpr int kFull = (TN / 4) * 4;
+  __host__ __device__ static constexpr int width(int j) {
+    return j < kFull ? 4 : ((TN - kFull >= 2 && j - kFull < 2) ? 2 : 1);
+  }
+  __host__ __device__ static constexpr int first(int j) {
+    return j < kFull ? (j / 4) * 4 : ((TN - kFull >= 2 && j - kFull < 2) ? kFull : j);
+  }
+  // first column of block j's group (groups never straddle a 64-column epilogue chunk)
+  __host__ __device__ static constexpr int base(int j) { return 16 * first(j); }
+};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// B fragments of one k-group: `row` points at column 0 of the lane's k row in the k-major image
+template <int TN>
+__device__ __forceinline__ void read_b_fragments(const float* __restrict__ row, int li,
+                                                 float (&b)[TN]) {
+  using G = ColGroups<TN>;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    if (G::first(j) != j) continue;
+    if (G::width(j) == 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + G::base(j) + 4 * li);
+      b[j] = v[0]; b[j + 1 < TN ? j + 1 : j] = v[1]; b[j + 2 < TN ? j + 2 : j] = v[2];
+      b[j + 3 < TN ? j + 3 : j] = v[3];
+    } else if (G::width(j) == 2) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(row + G::base(j) + 2 * li);
+      b[j] = v[0]; b[j + 1 < TN ? j + 1 : j] = v[1];
+    } else {
+      b[j] = row[G::base(j) + li];
+    }
+  }
+}
+
 template <int BM, int BN, bool NOREAD = false>
 __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const float* __restrict__ Bs,
                                            f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN],
@@ -141,9 +182,12 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const f
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
       a[i] = NOREAD ? (float)(lane + i) : As[ko * T::PA + 8 * ks + wave * T::WM + i * 16 + li];
+    if constexpr (NOREAD) {
 #pragma unroll
-    for (int j = 0; j < T::TN; ++j)
-      b[j] = NOREAD ? (float)(lane - j) : Bs[ko * T::PB + 8 * ks + j * 16 + li];
+      for (int j = 0; j < T::TN; ++j) b[j] = (float)(lane - j);
+    } else {
+      read_b_fragments<T::TN>(Bs + ko * T::PB + 8 * ks, li, b);
+    }
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
@@ -153,23 +197,37 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const f
 }
 
 // Accumulators -> LDS (column chunk `ch`) in [row][col] order.  C/D map of the 16x16 MFMA:
-// col = lane & 15, row = (lane >> 4) * 4 + reg.
+// row = (lane >> 4) * 4 + reg, column inside block j = lane & 15, i.e. (ColGroups) global column
+// base(j) + width(j) * (lane & 15) + (j - first(j)): one vector store per group and register.
 template <int BM, int BN>
 __device__ __forceinline__ void acc_to_lds(float* __restrict__ Cs,
                                            const f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN],
                                            int ch, int wave, int lane) {
   using T = Tile<BM, BN>;
-  constexpr int TPC = T::CCH / 16;  // 16-col tiles per chunk
+  using G = ColGroups<T::TN>;
+  constexpr int TPC = T::CCH / 16;  // 16-col blocks per chunk
+  const int li = lane & 15;
 #pragma unroll
   for (int i = 0; i < T::TM; ++i)
 #pragma unroll
     for (int jj = 0; jj < TPC; ++jj) {
       const int j = ch * TPC + jj;
-      if (j < T::TN) {
+      if (j < T::TN && G::first(j) == j) {
+        const int c0 = G::base(j) - ch * T::CCH;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          Cs[(wave * T::WM + i * 16 + (lane >> 4) * 4 + r) * T::PC + jj * 16 + (lane & 15)] =
-              acc[i][j][r];
+        for (int r = 0; r < 4; ++r) {
+          float* dst = Cs + (wave * T::WM + i * 16 + (lane >> 4) * 4 + r) * T::PC + c0;
+          if (G::width(j) == 4) {
+            *reinterpret_cast<f32x4*>(dst + 4 * li) =
+                f32x4{acc[i][j][r], acc[i][j + 1 < T::TN ? j + 1 : j][r],
+                      acc[i][j + 2 < T::TN ? j + 2 : j][r], acc[i][j + 3 < T::TN ? j + 3 : j][r]};
+          } else if (G::width(j) == 2) {
+            *reinterpret_cast<f32x2*>(dst + 2 * li) =
+                f32x2{acc[i][j][r], acc[i][j + 1 < T::TN ? j + 1 : j][r]};
+          } else {
+            dst[li] = acc[i][j][r];
+          }
+        }
       }
     }
 }
@@ -520,15 +578,14 @@ __device__ __forceinline__ void pipelined_k_loop(int nk, float* lds,
   constexpr int NQ = T::TM * T::TN;            // MFMAs per k-group
   const int kk = lane >> 4, li = lane & 15;
   const int a_base = kk * T::PA + wave * T::WM + li;
-  const int b_base = T::A_SZ + kk * T::PB + li;
+  const int b_base = T::A_SZ + kk * T::PB;
   float fa[2][T::TM], fb[2][T::TN];
   auto read_a = [&](const float* buf, int g, float (&a)[T::TM]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < T::TM; ++i) a[i] = buf[a_base + g * (4 * T::PA + 8) + i * 16];
   };
   auto read_b = [&](const float* buf, int g, float (&b)[T::TN]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < T::TN; ++j) b[j] = buf[b_base + g * (4 * T::PB + 8) + j * 16];
+    read_b_fragments<T::TN>(buf + b_base + g * (4 * T::PB + 8), li, b);
   };
   // slots (index of the MFMA within its k-group) behind which the side work is issued
   constexpr int Q_RB = NQ > 1 ? 1 : 0, Q_LA = NQ > 2 ? 2 : NQ - 1, Q_LB = NQ > 4 ? 4 : NQ - 1;
@@ -606,15 +663,14 @@ __device__ __forceinline__ void pipelined_k_loop_pairs(
   constexpr int NQ = T::TM * T::TN;
   const int kk = lane >> 4, li = lane & 15;
   const int a_base = kk * T::PA + wave * T::WM + li;
-  const int b_base = T::A_SZ + kk * T::PB + li;
+  const int b_base = T::A_SZ + kk * T::PB;
   float fa[2][T::TM], fb[2][T::TN];
   auto read_a = [&](const float* buf, int g, float (&a)[T::TM]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < T::TM; ++i) a[i] = buf[a_base + g * (4 * T::PA + 8) + i * 16];
   };
   auto read_b = [&](const float* buf, int g, float (&b)[T::TN]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < T::TN; ++j) b[j] = buf[b_base + g * (4 * T::PB + 8) + j * 16];
+    read_b_fragments<T::TN>(buf + b_base + g * (4 * T::PB + 8), li, b);
   };
   constexpr int Q_RB = NQ > 1 ? 1 : 0, Q_LA = NQ > 2 ? 2 : NQ - 1, Q_LB = NQ > 4 ? 4 : NQ - 1;
   f32x4 ra0[AS], ra1[AS], ra2[AS], ra3[AS];
@@ -718,6 +774,9 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
   static_assert(!AFF || (PIPE && !BTRANS && ABL == 0), "AFF: forward, pipelined loop only");
   constexpr int MAXTAPS = KS * KS;  // KS only bounds the tap loop and tags the kernel name
   const int ntaps = p.kh_n * p.kw_n;
+  unsigned long long st_entry = 0;
+  if constexpr (ABL == 9) st_entry = __builtin_amdgcn_s_memrealtime();
+  (void)st_entry;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // 1-D grid over (split, tile), split-major, remapped so that every XCD owns one contiguous run:
@@ -1013,7 +1072,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
       unsigned long long* o = reinterpret_cast<unsigned long long*>(keep) + ((long)blockIdx.x * 4 + wave) * 8;
-      o[0] = st_k0; o[1] = st_l1 - st_l0; o[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32) | __builtin_amdgcn_s_getreg(63508); o[3] = r_end;
+      o[0] = st_k0; o[1] = st_l1 - st_l0; o[2] = st_entry; o[3] = r_end;
       o[4] = d_load; o[5] = d_mfma; o[6] = d_store; o[7] = d_bar;
     }
   } else {
