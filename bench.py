@@ -57,6 +57,10 @@ def parse_args():
     ap.add_argument("--no-check", action="store_true",
                     help="skip the oracle check of the first step (diagnostics only)")
     ap.add_argument("--no-k3-timer", action="store_true")
+    ap.add_argument("--step-graphs", action="store_true",
+                    help="replay recurring subnets' training step from a captured HIP graph "
+                         "(IterBasedRunner.train_iter; off by default: slower on ROCm 7.2, see "
+                         "DESIGN.md); diagnostics / A-B only")
     ap.add_argument("--crop", default=None,
                     help="HxW override of the crop size (diagnostics only, e.g. 64x128 makes the GPU "
                          "work negligible and exposes the host cost per step; the headline "
@@ -314,6 +318,15 @@ def main():
     runner.register_hook(ArenaOptimizerHook())
     runner.call_hook("before_run")
     loader = SyntheticLoader(bs, size, num_classes=19, seed=args.seed, rank=rank, device=dev)
+    if args.step_graphs:
+        runner.graphs_enabled = True
+    # Start-up, untimed: capture the HIP graphs of the train sampler's named anchor subnets (they
+    # recur; random subnets never do and stay eager).  Each capture is one ordinary training step on
+    # a synthetic batch, like a warm-up step.  One rank only: see IterBasedRunner.train_iter.
+    graphs_built = 0
+    if runner.graphs_enabled and world == 1:
+        metas = [fixed_meta] if fixed_meta is not None else list(sampler.model_samplers[0].anchors)
+        graphs_built = runner.prepare_graphs(metas, make_batch(bs, size[0], size[1], 19, 12345, dev))
 
     for _ in range(args.warmup):
         runner.train_iter(next(loader))
@@ -325,6 +338,7 @@ def main():
         sampler.seed(args.seed)
         if instrumented:
             lib.check(L.gs_k3_timer_enable(1), "gs_k3_timer_enable")
+        runner.graphs_paused = bool(instrumented)   # HIP-event timers cannot sit inside a graph
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -337,14 +351,19 @@ def main():
         dt = time.perf_counter() - t0
         if instrumented:
             lib.check(L.gs_k3_timer_enable(0), "gs_k3_timer_enable")
+        runner.graphs_paused = False
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
+    call_prof = None
     if runner.host_prof is not None:
         runner.host_prof.clear()
+        call_prof = lib.enable_call_profile()
+        for rec in call_prof.values():
+            rec[0], rec[1] = 0, 0.0
     arch_log_start = runner.iter
     bytes0 = reducer.bytes_reduced
     prof = None
@@ -369,6 +388,13 @@ def main():
         n = max(hp.pop("iters", 1), 1)
         print("host ms/iter: " + ", ".join("%s %.2f" % (k, 1e3 * v / n) for k, v in hp.items()),
               file=sys.stderr)
+        if call_prof:
+            tot = sum(v[1] for v in call_prof.values())
+            cnt = sum(v[0] for v in call_prof.values())
+            print("  inside the C-ABI: %.2f ms/iter over %.0f calls/iter; top: " % (1e3 * tot / n, cnt / n)
+                  + ", ".join("%s %.0fx%.1fus" % (k[3:], v[0] / n, 1e6 * v[1] / max(v[0], 1))
+                              for k, v in sorted(call_prof.items(), key=lambda kv: -kv[1][1])[:12]),
+                  file=sys.stderr)
     k3 = None
     if not args.no_k3_timer:
         # separate pass over the same draws with HIP events on the launch stream around every
@@ -405,6 +431,10 @@ def main():
                 "parallelism": "dp%d" % world,
                 "allreduce_bytes_per_step_per_rank": int(bytes_per_step),
                 "last_loss": round(loss, 5),
+                "step_graphs": dict(runner.graph_stats, built_at_startup=graphs_built,
+                                    what="HIP-graph replay of recurring subnets' whole training "
+                                         "step (same kernels as the eager step); counts cover "
+                                         "start-up, warm-up and the timed steps"),
             },
             "check": check,
         }

@@ -24,6 +24,7 @@ import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
 from ..hip import ops
+from ..hip import runtime as _runtime
 from ..hip.runtime import round_up, tape_function
 from .dynamic import DynamicMixin
 from .registry import Registry, build_from_cfg
@@ -252,16 +253,36 @@ class DynamicBatchNorm2d(_BatchNorm, DynamicMixin):
         if c > self.num_features:
             raise ValueError("input has %d channels, norm supports at most %d" % (c, self.num_features))
         training = self.training
-        return ops.BNParams(self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                            self.momentum, training,
-                            process_group=self._process_group() if training else None,
-                            num_batches_tracked=self._count_batch
-                            if self.num_batches_tracked is not None else None)
+        # (one BNParams per mode, reused: building it walks nn.Module.__getattr__ five times.  The
+        # cache is dropped whenever parameters / buffers may have been replaced.)
+        cache = self.__dict__.get("_bnp_cache")
+        if cache is None:
+            cache = self.__dict__["_bnp_cache"] = {}
+        bnp = cache.get(training)
+        if bnp is None:
+            bnp = cache[training] = ops.BNParams(
+                self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
+                training, num_batches_tracked=self._count_batch
+                if self.num_batches_tracked is not None else None)
+        bnp.process_group = self._process_group() if (training and self.sync is not None) else None
+        return bnp
+
+    def _apply(self, fn, recurse=True):
+        self.__dict__.pop("_bnp_cache", None)
+        return super()._apply(fn, recurse)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.__dict__.pop("_bnp_cache", None)
+        super()._load_from_state_dict(*args, **kwargs)
 
     def _count_batch(self):
         """num_batches_tracked += 1 without a device op per BN per step: counted on the host and
         folded into the buffer whenever it is read through state_dict()."""
-        self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
+        d = self.__dict__   # (nn.Module.__setattr__ costs 3 us; this runs once per BN layer and step)
+        d["_nbt_pending"] = d.get("_nbt_pending", 0) + 1
+        log = _runtime.CAPTURE_LOG
+        if log is not None:   # a captured step graph repeats this count at every replay
+            log.append(self)
 
     def flush_counters(self):
         pending = getattr(self, "_nbt_pending", 0)
@@ -287,6 +308,7 @@ class DynamicBatchNorm2d(_BatchNorm, DynamicMixin):
         if self.num_features == c:
             return
         self.num_features = c
+        self.__dict__.pop("_bnp_cache", None)
         if self.affine:
             self.weight = nn.Parameter(self.weight.data[:c].clone(), self.weight.requires_grad)
             self.bias = nn.Parameter(self.bias.data[:c].clone(), self.bias.requires_grad)
@@ -335,6 +357,9 @@ def build_activation_layer(cfg):
     return build_from_cfg(cfg, ACTIVATION_LAYERS)
 
 
+_NO_FUSED_CALLS = os.environ.get("GS_NO_FUSED_CALLS") is not None
+
+
 def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=None, defer=False,
                 owns_input_grad=False):
     """conv -> norm (+ residual) (+ ReLU).  ``defer``: leave the BN + ReLU to the consumer's operand
@@ -343,13 +368,19 @@ def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=No
     bias, widths that are not multiples of 4 and subnet extraction take the module-by-module path.
     Both paths launch the same kernels."""
     c = conv.width_state
-    fused = (conv.bias is None and c % 4 == 0 and not getattr(conv, "_deploying", False)
-             and not getattr(norm, "_deploying", False) and os.environ.get("GS_NO_FUSED_CALLS") is None)
+    cd = conv.__dict__
+    weight = conv._parameters["weight"]
+    fused = (conv._parameters["bias"] is None and c % 4 == 0 and not cd.get("_deploying", False)
+             and not norm.__dict__.get("_deploying", False) and not _NO_FUSED_CALLS)
     if fused:
         bnp = norm.bn_params(c)
         if bnp.process_group is None:
-            conv._check_layout()
-            return ops.conv_bn(tape, x, conv.weight, c, bnp, conv.stride, conv.padding,
+            # the HWIO layout check touches five strides: redo it only when the storage moved
+            if cd.get("_layout_ptr") != weight.data_ptr():
+                conv._check_layout()
+                weight = conv._parameters["weight"]
+                cd["_layout_ptr"] = weight.data_ptr()
+            return ops.conv_bn(tape, x, weight, c, bnp, conv.stride, conv.padding,
                                conv.dilation, relu=relu, residual=residual, out=out, tag=tag,
                                defer=defer, owns_input_grad=owns_input_grad)
     y = conv.forward_act(tape, x, tag=tag)

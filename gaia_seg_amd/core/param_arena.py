@@ -104,11 +104,20 @@ class ParamArena:
             for a, b in ranges:
                 self.flat_grad[a:b].zero_()
 
-    def sgd_step(self, ranges, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, zero_grad=False):
-        """torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov=False) on the ranges."""
+    def sgd_step(self, ranges, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, zero_grad=False,
+                 hyper=None):
+        """torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov=False) on the ranges.
+        ``hyper``: device tensor {lr, momentum, weight_decay, grad_scale} read by the kernel at run
+        time instead of the by-value arguments (step graphs, core/runner.py)."""
         L = _lib.load()
         st = current_stream_ptr()
         pb, gb, mb = self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.flat_mom.data_ptr()
+        if hyper is not None:
+            hp = hyper.data_ptr()
+            for a, b in ranges:
+                _lib.check(L.gs_sgd_step_hyper(pb + 4 * a, gb + 4 * a, mb + 4 * a, b - a, hp,
+                                               1 if zero_grad else 0, st), "gs_sgd_step_hyper")
+            return
         for a, b in ranges:
             _lib.check(L.gs_sgd_step(pb + 4 * a, gb + 4 * a, mb + 4 * a, b - a, lr, momentum,
                                      weight_decay, grad_scale, 1 if zero_grad else 0, st),

@@ -20,6 +20,8 @@ from .model_space import arch_key
 
 
 class Hook:
+    in_graph = False   # True: after_train_iter only enqueues device work and may be graph-captured
+
     def before_run(self, runner):
         pass
 
@@ -76,6 +78,8 @@ class FixedLrUpdaterHook(Hook):
 class ArenaOptimizerHook(Hook):
     """OptimizerHook for the flat-arena SGD: the step touches only the active subnet's ranges."""
 
+    in_graph = True   # backward + SGD are part of a captured step graph (IterBasedRunner)
+
     def __init__(self, grad_clip=None):
         if grad_clip is not None:
             raise NotImplementedError("grad_clip is not configured by the in-tree configs")
@@ -99,13 +103,15 @@ class ArenaOptimizerHook(Hook):
             # gradients of everything behind the checkpoint are final once the side stream has passed
             # it: update those parameters while the stem / stage-1 weight gradients still run
             torch.cuda.current_stream().wait_event(ck)
-            runner.arena.sgd_step(early, runner.lr, runner.momentum, runner.weight_decay, scale, True)
+            runner.arena.sgd_step(early, runner.lr, runner.momentum, runner.weight_decay, scale, True,
+                                  hyper=runner.hyper)
             ops.join_side_streams()
-            runner.arena.sgd_step(late, runner.lr, runner.momentum, runner.weight_decay, scale, True)
+            runner.arena.sgd_step(late, runner.lr, runner.momentum, runner.weight_decay, scale, True,
+                                  hyper=runner.hyper)
         else:
             ops.join_side_streams()
             runner.arena.sgd_step(runner.active_ranges, runner.lr, runner.momentum,
-                                  runner.weight_decay, scale, True)
+                                  runner.weight_decay, scale, True, hyper=runner.hyper)
         # the step cleared exactly the ranges backward wrote: the next zero_grad has nothing to do
         runner.arena.grads_clean = True
         if prof is not None:
@@ -148,6 +154,13 @@ class CheckpointHook(Hook):
                             optimizer=runner.arena, meta=dict(runner.meta or {}, iter=runner.iter + 1))
 
 
+class _StepGraph:
+    __slots__ = ("graph", "static", "outputs", "counters")
+
+    def __init__(self, graph, static, outputs, counters):
+        self.graph, self.static, self.outputs, self.counters = graph, static, outputs, counters
+
+
 class IterBasedRunner:
     """``run(data_loaders, workflow)`` drives ``model.train_step`` for ``max_iters`` iterations."""
 
@@ -170,6 +183,17 @@ class IterBasedRunner:
         self._split_cache = {}
         # GS_HOST_PROF=1: accumulate host-side seconds per phase of train_iter (diagnostics)
         self.host_prof = {} if os.environ.get("GS_HOST_PROF") else None
+        # ---- step graphs (see train_iter) ----
+        # off by default: on ROCm 7.2 hipGraphLaunch spends as much host time per kernel node as the
+        # eager path spends per launch (r02: 8.3 ms to launch the 560-node R50 step graph against
+        # 8.0 ms of eager host work), so a replay neither frees the host nor closes launch gaps
+        self.graphs_enabled = os.environ.get("GS_STEP_GRAPH", "0") == "1"
+        self.graphs_paused = False     # e.g. while HIP-event timers are recorded inside the step
+        self.max_graphs = int(os.environ.get("GS_STEP_GRAPH_MAX", "8"))
+        self._graphs = OrderedDict()   # graph key -> _StepGraph (LRU)
+        self._arch_seen = {}           # arch key -> eager steps run with it
+        self.hyper = None              # device {lr, momentum, weight_decay, grad_scale} (graphs on)
+        self.graph_stats = {"captured": 0, "replayed": 0, "eager": 0}
         self.set_arch(None)
 
     def register_hook(self, hook):
@@ -220,6 +244,113 @@ class IterBasedRunner:
             self._split_cache[key] = out
         return out
 
+    # ------------------------------------------------------------------------------------------
+    # Step graphs.  A training step of a given subnet on a given batch shape is a fixed sequence of
+    # ~600-1100 kernel launches (forward, backward, SGD) whose only step-dependent inputs are the
+    # batch and the learning rate.  For subnets that come back (the named anchors of the train
+    # sampler, or any subnet seen before) the whole step is captured ONCE into a HIP graph
+    # (torch.cuda.CUDAGraph: stream capture of the launches the C-ABI makes on torch's current
+    # stream and on the weight-gradient side stream) and replayed afterwards: the batch is copied
+    # into the graph's static input tensors, lr / momentum / weight decay sit in a 16-byte device
+    # buffer the SGD kernel reads (gs_sgd_step_hyper), and one graph launch replaces the host-side
+    # walk over the modules.  Same kernels, same order, same results as the eager step (bit-identical:
+    # tests/test_runner_gpu.py).  Never-repeating random subnets, multi-rank runs (RCCL launches are
+    # left out of capture), SyncBN groups and diagnostic traces keep the eager path.
+    # MEASURED (r02, MI355X, ROCm 7.2): the graph launch itself costs the host ~15 us per kernel node,
+    # i.e. as much as the eager path; R50 192.9 img/s replayed vs 198.5 eager, the sampled mix loses
+    # 40 % (switching between large graphs).  The feature is therefore OPT-IN (GS_STEP_GRAPH=1).
+    # ------------------------------------------------------------------------------------------
+    def _graph_key(self, data_batch):
+        from ..hip import ops
+        if (not self.graphs_enabled or self.graphs_paused or self.arch_key is None
+                or self.arch_key == ("current",) or gdist.world_size() != 1
+                or ops.RELU_TRACE is not None or ops.POOL_TRACE is not None or ops.TIMER is not None):
+            return None
+        sig = []
+        for k in sorted(data_batch):
+            v = data_batch[k]
+            if torch.is_tensor(v):
+                if not v.is_cuda:
+                    return None
+                sig.append((k, tuple(v.shape), v.dtype))
+        return (self.arch_key, tuple(sig), self.model.training)
+
+    def _write_hyper(self):
+        """lr / momentum / weight decay / gradient scale of THIS step -> the device buffer."""
+        from ..hip import lib as _lib
+        from ..hip.runtime import current_stream_ptr
+        if self.hyper is None:
+            self.hyper = torch.zeros(4, dtype=torch.float32, device=self.arena.flat_param.device)
+        _lib.check(_lib.load().gs_sgd_set_hyper(self.hyper.data_ptr(), self.lr, self.momentum,
+                                                self.weight_decay, 1.0 / gdist.world_size(),
+                                                current_stream_ptr()), "gs_sgd_set_hyper")
+
+    def _after_hooks(self, in_graph):
+        for h in self.hooks:
+            if bool(getattr(h, "in_graph", False)) == in_graph:
+                h.after_train_iter(self)
+
+    def _capture_step(self, key, data_batch):
+        """Capture forward + backward + SGD of the current subnet into a graph, then run it once."""
+        from ..hip import ops, runtime
+        dev = self.arena.flat_param.device
+        static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_batch.items()}
+        ops.reserve_workspaces(dev)   # no workspace may be (re)allocated inside the capture
+        graph = torch.cuda.CUDAGraph()
+        runtime.CAPTURE_LOG = []
+        try:
+            with torch.cuda.graph(graph):
+                self.outputs = self.model.train_step(static, None)
+                self._after_hooks(True)
+            counters = runtime.CAPTURE_LOG
+        finally:
+            runtime.CAPTURE_LOG = None
+        entry = _StepGraph(graph, static, self.outputs, counters)
+        self._graphs[key] = entry
+        while len(self._graphs) > self.max_graphs:
+            self._graphs.popitem(last=False)
+        self.graph_stats["captured"] += 1
+        graph.replay()                 # the capture only recorded the step: this performs it
+        return entry
+
+    def _replay_step(self, entry, data_batch):
+        for k, v in entry.static.items():
+            if torch.is_tensor(v):
+                v.copy_(data_batch[k], non_blocking=True)
+        entry.graph.replay()
+        for m in entry.counters:       # host-side effects of the step that the graph cannot carry
+            m._nbt_pending = getattr(m, "_nbt_pending", 0) + 1
+        self.outputs = entry.outputs
+        self.arena.grads_clean = True  # (the captured SGD step clears the gradients it consumed)
+        self.graph_stats["replayed"] += 1
+
+    def prepare_graphs(self, metas, data_batch):
+        """Capture the step graphs of the given subnets ahead of time (e.g. the sampler's anchors at
+        start-up) instead of at their first occurrence.  Every capture performs one real training
+        step on ``data_batch``; the architecture in place before the call is restored."""
+        keep = self.arch_meta
+        done = 0
+        for meta in metas:
+            self.set_arch(meta)
+            gkey = self._graph_key(data_batch)
+            if gkey is None or gkey in self._graphs:
+                continue
+            for eager in ((True, False) if self.graph_stats["eager"] == 0 else (False,)):
+                self._write_hyper()
+                self.arena.zero_grad(self.active_ranges)
+                self.arena.grads_clean = False
+                self.reducer.begin(self.trainable_params, self.arch_key)
+                if eager:
+                    self.outputs = self.model.train_step(data_batch, None)
+                    self._after_hooks(True)
+                    self.graph_stats["eager"] += 1
+                else:
+                    self._capture_step(gkey, data_batch)
+                    done += 1
+        if keep is not None:
+            self.set_arch(keep)
+        return done
+
     def train_iter(self, data_batch):
         prof = self.host_prof
         t0 = time.perf_counter() if prof is not None else 0.0
@@ -227,14 +358,38 @@ class IterBasedRunner:
             self.model.train()
         self.call_hook("before_train_iter")
         t1 = time.perf_counter() if prof is not None else 0.0
-        self.arena.zero_grad(self.active_ranges)   # (a no-op after a clearing optimizer step)
-        self.arena.grads_clean = False             # backward is about to write gradients
-        self.reducer.begin(self.trainable_params,
-                           self.arch_key if self.arch_key != ("current",) else None)
-        t2 = time.perf_counter() if prof is not None else 0.0
-        self.outputs = self.model.train_step(data_batch, None)
-        t3 = time.perf_counter() if prof is not None else 0.0
-        self.call_hook("after_train_iter")
+        gkey = self._graph_key(data_batch)
+        if self.graphs_enabled and gdist.world_size() == 1:
+            self._write_hyper()
+        entry = self._graphs.get(gkey) if gkey is not None else None
+        t2 = t1
+        if entry is not None:
+            self._graphs.move_to_end(gkey)
+            self._replay_step(entry, data_batch)
+            t3 = time.perf_counter() if prof is not None else 0.0
+        else:
+            self.arena.zero_grad(self.active_ranges)   # (a no-op after a clearing optimizer step)
+            self.arena.grads_clean = False             # backward is about to write gradients
+            self.reducer.begin(self.trainable_params,
+                               self.arch_key if self.arch_key != ("current",) else None)
+            t2 = time.perf_counter() if prof is not None else 0.0
+            # capture at first sight what is known to come back (named anchors), anything else the
+            # second time it shows up; the very first step of a process always runs eagerly (module
+            # loading and lazily created handles must not happen inside a capture)
+            known = self.arch_name != "random" or self._arch_seen.get(self.arch_key, 0) > 0
+            if gkey is not None and known and self.graph_stats["eager"] > 0:
+                self._capture_step(gkey, data_batch)
+                t3 = time.perf_counter() if prof is not None else 0.0
+            else:
+                self.outputs = self.model.train_step(data_batch, None)
+                t3 = time.perf_counter() if prof is not None else 0.0
+                self._after_hooks(True)
+                self.graph_stats["eager"] += 1
+                if gkey is not None:
+                    self._arch_seen[self.arch_key] = self._arch_seen.get(self.arch_key, 0) + 1
+                    if len(self._arch_seen) > 4096:
+                        self._arch_seen.clear()
+        self._after_hooks(False)
         if prof is not None:
             t4 = time.perf_counter()
             for k, v in (("hooks_before", t1 - t0), ("zero+begin", t2 - t1), ("forward", t3 - t2),

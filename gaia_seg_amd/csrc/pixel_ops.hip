@@ -346,10 +346,15 @@ __global__ __launch_bounds__(256) void scale_nc_kernel(const float* x, int ldx,
 // torch.optim.SGD step over a flat range (cfg: pspnet_ar50to101v2_gsync.py:175)
 // ZERO: the gradient is cleared once it has been consumed (the next step then needs no zero_grad
 // fill kernels in front of its forward pass)
-template <bool ZERO>
+// HYPER: lr / momentum / weight decay / gradient scale are read from device memory at run time
+// (`hyper` = {lr, momentum, wd, gscale}), so that a captured hipGraph of the whole training step can
+// be replayed under a learning-rate schedule without re-capturing.
+template <bool ZERO, bool HYPER>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g,
                                                   float* __restrict__ m, long n4, float lr,
-                                                  float momentum, float wd, float gscale) {
+                                                  float momentum, float wd, float gscale,
+                                                  const float* __restrict__ hyper) {
+  if (HYPER) { lr = hyper[0]; momentum = hyper[1]; wd = hyper[2]; gscale = hyper[3]; }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (long)gridDim.x * blockDim.x) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
@@ -666,12 +671,43 @@ extern "C" int gs_sgd_step(float* param, float* grad, float* momentum_buf, int64
   if ((n & 3) || !aligned16(param) || !aligned16(grad) || !aligned16(momentum_buf))
     return GS_E_ALIGN;
   if (zero_grad)
-    hipLaunchKernelGGL(sgd_kernel<true>, dim3(stream_grid(n >> 2, 256)), dim3(256), 0,
+    hipLaunchKernelGGL((sgd_kernel<true, false>), dim3(stream_grid(n >> 2, 256)), dim3(256), 0,
                        as_stream(stream), param, grad, momentum_buf, (long)(n >> 2), lr, momentum,
-                       weight_decay, grad_scale);
+                       weight_decay, grad_scale, (const float*)nullptr);
   else
-    hipLaunchKernelGGL(sgd_kernel<false>, dim3(stream_grid(n >> 2, 256)), dim3(256), 0,
+    hipLaunchKernelGGL((sgd_kernel<false, false>), dim3(stream_grid(n >> 2, 256)), dim3(256), 0,
                        as_stream(stream), param, grad, momentum_buf, (long)(n >> 2), lr, momentum,
-                       weight_decay, grad_scale);
+                       weight_decay, grad_scale, (const float*)nullptr);
+  return launch_status();
+}
+
+__global__ void set_hyper_kernel(float* hyper, float lr, float momentum, float wd, float gscale) {
+  hyper[0] = lr; hyper[1] = momentum; hyper[2] = wd; hyper[3] = gscale;
+}
+
+extern "C" int gs_sgd_set_hyper(float* hyper, float lr, float momentum, float weight_decay,
+                                float grad_scale, void* stream) {
+  if (!hyper) return GS_E_NULL;
+  if (!aligned16(hyper)) return GS_E_ALIGN;
+  hipLaunchKernelGGL(set_hyper_kernel, dim3(1), dim3(1), 0, as_stream(stream), hyper, lr, momentum,
+                     weight_decay, grad_scale);
+  return launch_status();
+}
+
+extern "C" int gs_sgd_step_hyper(float* param, float* grad, float* momentum_buf, int64_t n,
+                                 const float* hyper, int32_t zero_grad, void* stream) {
+  if (!param || !grad || !momentum_buf || !hyper) return GS_E_NULL;
+  if (n <= 0) return GS_E_BADARG;
+  if ((n & 3) || !aligned16(param) || !aligned16(grad) || !aligned16(momentum_buf) ||
+      !aligned16(hyper))
+    return GS_E_ALIGN;
+  if (zero_grad)
+    hipLaunchKernelGGL((sgd_kernel<true, true>), dim3(stream_grid(n >> 2, 256)), dim3(256), 0,
+                       as_stream(stream), param, grad, momentum_buf, (long)(n >> 2), 0.f, 0.f, 0.f,
+                       0.f, hyper);
+  else
+    hipLaunchKernelGGL((sgd_kernel<false, true>), dim3(stream_grid(n >> 2, 256)), dim3(256), 0,
+                       as_stream(stream), param, grad, momentum_buf, (long)(n >> 2), 0.f, 0.f, 0.f,
+                       0.f, hyper);
   return launch_status();
 }

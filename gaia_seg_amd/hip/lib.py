@@ -16,7 +16,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgaiaseg_hip.so")
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HipLibraryError(RuntimeError):
@@ -133,6 +133,8 @@ PROTOTYPES = {
     "gs_ohem_weights": (_i32, [_P, _i64, _i64, _f32, _i32, _P, _P, _sz, _P]),
     "gs_confusion_matrix": (_i32, [_P, _P, _i64, _i32, _i32, _P, _P]),
     "gs_sgd_step": (_i32, [_P, _P, _P, _i64, _f32, _f32, _f32, _f32, _i32, _P]),
+    "gs_sgd_step_hyper": (_i32, [_P, _P, _P, _i64, _P, _i32, _P]),
+    "gs_sgd_set_hyper": (_i32, [_P, _f32, _f32, _f32, _f32, _P]),
     "gs_debug_force_plan": (_i32, [_i32, _i32, _i32]),
     "gs_debug_query_plan": (_i32, [_i32, _i32, _i32, _i32, POINTER(_i32), POINTER(_i32), POINTER(_i32),
                                    POINTER(_i32)]),
@@ -194,6 +196,33 @@ def load():
                               % (lib.gs_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+CALL_PROFILE = None
+
+
+def enable_call_profile():
+    """Diagnostics (GS_HOST_PROF): time every call into the library on the host.  Returns the dict
+    {name: [calls, seconds]} that the wrappers fill; the seconds are host time inside the C-ABI call
+    (argument conversion + the HIP launches it makes), not device time."""
+    global CALL_PROFILE
+    import time
+    lib = load()
+    if CALL_PROFILE is not None:
+        return CALL_PROFILE
+    CALL_PROFILE = {}
+    for name in PROTOTYPES:
+        fn = getattr(lib, name)
+        rec = CALL_PROFILE.setdefault(name, [0, 0.0])
+
+        def wrapped(*a, _fn=fn, _rec=rec, _t=time.perf_counter):
+            t0 = _t()
+            r = _fn(*a)
+            _rec[1] += _t() - t0
+            _rec[0] += 1
+            return r
+        setattr(lib, name, wrapped)
+    return CALL_PROFILE
 
 
 def error_string(code):

@@ -69,6 +69,8 @@ def flush_wgrads():
             ws_s = _side_workspace(need, dev, side)
             dy.record_stream(side)
             x.t.record_stream(side)
+            # (descriptors are shared per layer: the operand-loader coefficients are per call)
+            d.in_affine = x.affine.data_ptr() if x.affine is not None else None
             _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
                                          ws_s.data_ptr(), ws_s.numel(), side.cuda_stream),
                        "gs_conv2d_wgrad")
@@ -126,6 +128,14 @@ def _side_workspace(need, dev, side):
         return _ws_side.get(need, dev)
 
 
+def reserve_workspaces(dev, nbytes=192 << 20):
+    """Size the main and the side-stream scratch buffers for the largest request a convolution of
+    the supernet can make (96 MiB of split-K slabs + reduction partials), so that a step graph
+    capture never sees a workspace being (re)allocated."""
+    _ws.get(nbytes, dev)
+    _side_workspace(nbytes, dev, _side_stream(dev))
+
+
 def _L():
     return _lib.load()
 
@@ -136,6 +146,9 @@ def ensure_grad(param):
     Parameters with a padded / permuted physical layout (HWIO conv weights, the padded conv_seg
     bias) carry a ``_gs_grad_factory`` that allocates matching storage; with a ParamArena installed
     the gradients already exist as views of the flat gradient buffer."""
+    g = param.grad
+    if g is not None and g.stride() == param.stride():   # the common case, checked first
+        return g
     if param.grad is None:
         factory = getattr(param, "_gs_grad_factory", None)
         if factory is not None:
@@ -149,7 +162,7 @@ def ensure_grad(param):
 
 
 def _notify(param):
-    hook = getattr(param, "_gs_grad_ready", None)
+    hook = param.__dict__.get("_gs_grad_ready")
     if hook is not None:
         hook(param)
 
@@ -513,6 +526,49 @@ BNBWD_FUSE = os.environ.get("GS_NO_BNBWD_FUSE") is None
 BNBWD_FUSED_COUNT = 0   # diagnostics: how many BN-backward reductions ran inside a dgrad epilogue
 
 
+class _ConvBnPlan:
+    """Everything about one conv + BN layer call that depends only on the layer and on the geometry
+    of its input: the descriptor, the BN argument block, sizes.  Cached on the weight Parameter per
+    (input geometry, active widths, flags): a supernet layer sees a handful of them, and building
+    the two ctypes structures was a third of the host time of a layer call.  Pointers (the input's
+    deferred-BN coefficients, the BN parameters — an arena rebuild moves them) are NOT part of the
+    plan: they are written into the cached structures at every use, forward and backward."""
+    __slots__ = ("d", "args", "need", "n", "ho", "wo", "rows", "C", "use_batch", "affine_ok")
+
+
+def _conv_bn_plan(L, x, weight, co_eff, bn, stride, pad, dil, relu, tag, use_batch):
+    kh, kw = weight.shape[2], weight.shape[3]
+    if x.nchw_image:
+        n, _, h, w = x.t.shape
+    else:
+        n, h, w = x.N, x.H, x.W
+    pl = _ConvBnPlan()
+    pl.n = n
+    pl.ho, pl.wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(w, kw, stride, pad, dil)
+    pl.rows = n * pl.ho * pl.wo
+    pl.C = co_eff
+    pl.use_batch = use_batch
+    pl.d = d = _conv_desc(x, weight, co_eff, stride, pad, dil, round_up(co_eff, 4),
+                          role=1 if tag == "k3" else 0)
+    pl.affine_ok = bool(L.gs_conv2d_in_affine_supported(ctypes.byref(d)))
+    pl.need = L.gs_conv_bn_workspace_bytes(ctypes.byref(d))
+    pl.args = args = _lib.BnArgs()
+    args.eps = bn.eps
+    args.momentum = bn.momentum if bn.momentum is not None else 0.1
+    args.use_batch_stats = 1 if use_batch else 0
+    args.update_running = 1 if (bn.training and bn.running_mean is not None) else 0
+    args.relu = 1 if relu else 0
+    return pl
+
+
+def _bn_pointers(args, bn):
+    w, b, rm, rv = bn.weight, bn.bias, bn.running_mean, bn.running_var
+    args.gamma = w.data_ptr() if w is not None else None
+    args.beta = b.data_ptr() if b is not None else None
+    args.running_mean = rm.data_ptr() if rm is not None else None
+    args.running_var = rv.data_ptr() if rv is not None else None
+
+
 def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
             tag=None, defer=False, owns_input_grad=False):
     """z = act(BN(conv(x, weight[:co, :x.C])) (+ residual)) through ONE library call per direction
@@ -531,47 +587,43 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
     backward finds them in ``x.bnb_sums`` and skips its reduction pass over dz and y."""
     L = _L()
     co_eff = round_up(co, 4)
+    if co_eff != co:   # channel counts that are not multiples of 4 keep the two-step path
+        raise ValueError("conv_bn needs an output width that is a multiple of 4, got %d" % co)
     dev = x.t.device
-    kh, kw = weight.shape[2], weight.shape[3]
-    if x.nchw_image:
-        n, _, h, w = x.t.shape
-    else:
-        n, h, w = x.N, x.H, x.W
     defer = bool(defer and DEFER_BN and relu and residual is None and out is None)
-    ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(w, kw, stride, pad, dil)
-    rows = n * ho * wo
     use_batch = bn.training or bn.running_mean is None
-    if use_batch and rows <= 1:
+    plans = weight.__dict__.get("_gs_plans")
+    if plans is None:
+        plans = weight._gs_plans = {}
+    pl = None
+    for _ in range(2):   # (second round: the deferred input had to be written out)
+        key = None if x.nchw_image else (x.N, x.H, x.W, x.C, x.ld, stride, pad, dil, co, relu, tag,
+                                         bn.training, use_batch, bn.momentum, bn.eps)
+        pl = plans.get(key) if key is not None else None
+        if pl is None:
+            pl = _conv_bn_plan(L, x, weight, co_eff, bn, stride, pad, dil, relu, tag, use_batch)
+            if key is not None:
+                if len(plans) > 64:
+                    plans.clear()
+                plans[key] = pl
+        if x.affine is None or pl.affine_ok:
+            break
+        x = materialize(tape, x)
+    if use_batch and pl.rows <= 1:
         raise ValueError("Expected more than 1 value per channel when training, got input size %s"
-                         % ((n, co, ho, wo),))
-    y = Act.empty(n, ho, wo, co, dev)
-    if x.affine is not None:
-        d = _conv_desc(x, weight, co_eff, stride, pad, dil, y.ld, role=1 if tag == "k3" else 0)
-        if not L.gs_conv2d_in_affine_supported(ctypes.byref(d)):
-            x = materialize(tape, x)
-    d = _conv_desc(x, weight, co_eff, stride, pad, dil, y.ld, role=1 if tag == "k3" else 0)
+                         % ((pl.n, co, pl.ho, pl.wo),))
+    d, args, need, C, rows = pl.d, pl.args, pl.need, pl.C, pl.rows
+    y = Act.empty(pl.n, pl.ho, pl.wo, co, dev)
     in_affine = x.affine   # kept alive by the backward closure
-    if in_affine is not None:
-        d.in_affine = in_affine.data_ptr()
+    d.in_affine = in_affine.data_ptr() if in_affine is not None else None
     if defer:
         out = y
     elif out is None:
-        out = Act.empty(n, ho, wo, co, dev)
-    C = co_eff
-    if y.C != C:   # channel counts that are not multiples of 4 keep the two-step path
-        raise ValueError("conv_bn needs an output width that is a multiple of 4, got %d" % co)
-    args = _lib.BnArgs()
-    args.gamma = bn.weight.data_ptr() if bn.weight is not None else None
-    args.beta = bn.bias.data_ptr() if bn.bias is not None else None
-    args.running_mean = bn.running_mean.data_ptr() if bn.running_mean is not None else None
-    args.running_var = bn.running_var.data_ptr() if bn.running_var is not None else None
-    args.eps = bn.eps
-    args.momentum = bn.momentum if bn.momentum is not None else 0.1
-    args.use_batch_stats = 1 if use_batch else 0
-    args.update_running = 1 if (bn.training and bn.running_mean is not None) else 0
-    args.relu = 1 if relu else 0
-    coeffs = torch.empty(4 * C, dtype=torch.float32, device=dev)
-    need = L.gs_conv_bn_workspace_bytes(ctypes.byref(d))
+        out = Act.empty(pl.n, pl.ho, pl.wo, co, dev)
+    _bn_pointers(args, bn)
+    # [scale | beta | mean | invstd][C] + a 2C slot for this BatchNorm's backward sums (filled by
+    # this layer's backward, or by its consumer's dgrad epilogue): one small allocation per layer
+    coeffs = torch.empty(6 * C, dtype=torch.float32, device=dev)
     ws = _ws.get(need, dev)
     _lib.check(L.gs_conv_bn_forward(ctypes.byref(d), x.ptr, weight.data_ptr(), ctypes.byref(args),
                                     residual.ptr if residual is not None else None,
@@ -589,6 +641,8 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
     if relu and use_batch and BNBWD_FUSE and tape.enabled and out.parent is None:
         out.bnb = (y, coeffs, 2 if residual is not None else 1, out if residual is not None else None)
     x_bnb = x.bnb if (owns_input_grad and BNBWD_FUSE and x.requires_grad) else None
+    if not tape.enabled:
+        return out
 
     def backward():
         dz = out.g
@@ -604,7 +658,7 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
         gbeta = ensure_grad(bn.bias) if bgrad_bn else None
         gw = ensure_grad(weight) if weight.requires_grad else None
         dy = torch.empty_like(y.t)
-        bsums = out.bnb_sums if sums_ready else torch.empty(2 * C, dtype=torch.float32, device=dev)
+        bsums_ptr = coeffs.data_ptr() + 16 * C
         acc = 0
         dx_ptr = None
         if x.requires_grad:
@@ -612,23 +666,25 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
             if not acc:
                 x.new_grad() if x.parent is None else _alloc_parent_grad(x)
             dx_ptr = x.g.data_ptr()
-        fuse, fused_flag, in_sums = None, None, None
+        fuse, fused_flag = None, None
         if x_bnb is not None and dx_ptr is not None and x.parent is None:
             py, pcoeffs, pmode, pact = x_bnb
-            in_sums = torch.empty(2 * x.C, dtype=torch.float32, device=dev)
             fused_flag = ctypes.c_int32(0)
             fuse = _lib.BnBwdFuse()
             fuse.y, fuse.ldy = py.ptr, py.ld
             fuse.act, fuse.ldact = (pact.ptr, pact.ld) if pact is not None else (None, 0)
-            fuse.coeffs, fuse.sums = pcoeffs.data_ptr(), in_sums.data_ptr()
+            pc = pcoeffs.data_ptr()
+            fuse.coeffs, fuse.sums = pc, pc + 16 * (pcoeffs.numel() // 6)   # the producer's sums slot
             fuse.fused = ctypes.pointer(fused_flag)
             fuse.mode, fuse.reserved = pmode, 0
         ws_b = _ws.get(need, dev)
         queued = SIDE_WGRAD and gw is not None
+        d.in_affine = in_affine.data_ptr() if in_affine is not None else None
+        _bn_pointers(args, bn)
         _lib.check(L.gs_conv_bn_backward(
             ctypes.byref(d), x.ptr, weight.data_ptr(), y.ptr, out.ptr, out.ld, coeffs.data_ptr(),
             ctypes.byref(args), dz.data_ptr(), dz.stride(2), mask, 1 if want_g else 0,
-            dy.data_ptr(), bsums.data_ptr(), ggamma.data_ptr() if wgrad_bn else None,
+            dy.data_ptr(), bsums_ptr, ggamma.data_ptr() if wgrad_bn else None,
             gbeta.data_ptr() if bgrad_bn else None,
             gw.data_ptr() if (gw is not None and not queued) else None,
             dx_ptr, acc, ws_b.data_ptr(), ws_b.numel(), None, 0, s, None,
@@ -637,7 +693,7 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
         if fuse is not None and fused_flag.value:
             global BNBWD_FUSED_COUNT
             BNBWD_FUSED_COUNT += 1
-            x.bnb_sums = in_sums     # x.g now holds the MASKED gradient of the producer's ReLU
+            x.bnb_sums = True        # x.g now holds the MASKED gradient of the producer's ReLU
         if wgrad_bn:
             _notify(bn.weight)
         if bgrad_bn:

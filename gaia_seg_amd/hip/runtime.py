@@ -43,6 +43,7 @@ class _Workspace:
 
     def __init__(self):
         self._buf = {}
+        self._retired = []   # outgrown buffers: captured step graphs may still point into them
 
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 256)
@@ -52,6 +53,8 @@ class _Workspace:
             # round up generously so later, larger requests rarely reallocate
             size = max(nbytes, 1 << 20)
             size = 1 << (size - 1).bit_length()
+            if buf is not None:
+                self._retired.append(buf)
             buf = torch.empty(size, dtype=torch.uint8, device=device)
             self._buf[key] = buf
         return buf
@@ -207,6 +210,10 @@ class Tape:
         else:
             _ops.join_side_streams()   # weight gradients queued on the side stream
 
+
+# While a training step is being captured into a HIP graph (core/runner.py) host-side effects that a
+# replay must repeat are logged here (BatchNorm layers whose num_batches_tracked counts the step).
+CAPTURE_LOG = None
 
 BACKWARD_PROFILE = None
 if __import__("os").environ.get("GS_CPROFILE"):

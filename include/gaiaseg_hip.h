@@ -433,6 +433,17 @@ int gs_confusion_matrix(const int64_t* pred, const int64_t* label, int64_t n, in
  * OptimizerHook's zero_grad -> backward -> step order). */
 int gs_sgd_step(float* param, float* grad, float* momentum_buf, int64_t n, float lr,
                 float momentum, float weight_decay, float grad_scale, int32_t zero_grad, void* stream);
+/* Same update with the hyper-parameters read from DEVICE memory when the kernel runs:
+ * hyper = {lr, momentum, weight_decay, grad_scale} (16-byte aligned).  The launch carries no
+ * step-dependent value, so a hipGraph captured around a whole training step (core/runner.py) can be
+ * replayed under the poly learning-rate schedule (PolyLrUpdaterHook) by rewriting 16 bytes. */
+/* Writes {lr, momentum, weight_decay, grad_scale} into that buffer in stream order (the values travel
+ * as kernel arguments: unlike an asynchronous copy from a reused host buffer, a launch that is still
+ * queued when the host moves on to the next step keeps its own values). */
+int gs_sgd_set_hyper(float* hyper, float lr, float momentum, float weight_decay, float grad_scale,
+                     void* stream);
+int gs_sgd_step_hyper(float* param, float* grad, float* momentum_buf, int64_t n, const float* hyper,
+                      int32_t zero_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Training input pipeline                                             */

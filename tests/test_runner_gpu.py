@@ -149,3 +149,41 @@ def test_checkpoint_keeps_momentum_by_name_in_oihw(hip_lib, tmp_path):
     with pytest.warns(UserWarning):
         runner3.resume(foreign)
     assert float(arena3.flat_mom.abs().max()) == 0.0
+
+
+def test_step_graph_replay_equals_the_eager_step(hip_lib):
+    """A recurring subnet's training step is captured into a HIP graph and replayed
+    (IterBasedRunner.train_iter): same kernels in the same order, so parameters, momentum, BN
+    statistics and the logged losses must be BIT-identical to the eager path — across alternating
+    subnets, a changing learning rate (the SGD kernel reads it from device memory) and changing
+    batches.  Dropout is switched off: the device RNG streams of a graph and of eager launches differ."""
+    from gaia_seg_amd.core.runner import PolyLrUpdaterHook
+    from gaia_seg_amd.models import build_segmentor
+
+    def run(graphs):
+        torch.manual_seed(0)
+        model = build_segmentor(copy.deepcopy(model_cfg(fcn_head(), aux=True))).cuda().train()
+        for h in (model.decode_head, model.auxiliary_head):
+            h.dropout = None
+        runner, arena = _runner(model)
+        runner.graphs_enabled = graphs
+        runner.register_hook(PolyLrUpdaterHook(power=0.9, min_lr=1e-4))
+        runner.call_hook("before_run")
+        logs = []
+        for it, name in enumerate(["sub", "min", "sub", "min", "sub", "sub", "min"]):
+            runner.set_arch(_anchor(name))
+            out = runner.train_iter(_batch(it))
+            logs.append({k: float(v) for k, v in out["log_vars"].items()})
+        torch.cuda.synchronize()
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        return sd, arena.flat_mom.detach().clone(), logs, dict(runner.graph_stats)
+
+    sd_e, mom_e, logs_e, st_e = run(False)
+    sd_g, mom_g, logs_g, st_g = run(True)
+    assert st_e == {"captured": 0, "replayed": 0, "eager": 7}
+    assert st_g == {"captured": 2, "replayed": 4, "eager": 1}, st_g   # (opt-in: GS_STEP_GRAPH=1)
+    assert logs_e == logs_g
+    assert torch.equal(mom_e, mom_g)
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
+    assert int(sd_g["backbone.bn1.num_batches_tracked"]) == 7
