@@ -543,11 +543,17 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
         # that input (conv2 / conv3 are the only consumers of theirs; conv1's input also feeds the
         # identity branch, whose gradient is in place before conv1's backward runs — unless a
         # projection shortcut consumes it too, which runs after conv1 in the reversed replay)
-        out = conv_bn_act(tape, self.conv1, self.norm1, x, relu=True,
-                          defer="conv2" in ops.DEFER_EDGES, owns_input_grad=self.downsample is None)
-        out = conv_bn_act(tape, self.conv2, self.norm2, out, relu=True, tag="k3",
-                          defer="conv3" in ops.DEFER_EDGES, owns_input_grad=True)
-        return conv_bn_act(tape, self.conv3, self.norm3, out, relu=True, residual=identity,
+        hot = self.__dict__.get("_hot")   # (six nn.Module.__getattr__ walks per block otherwise)
+        if hot is None:
+            hot = self.__dict__["_hot"] = (self.conv1, self.norm1, self.conv2, self.norm2,
+                                           self.conv3, self.norm3)
+        conv1, norm1, conv2, norm2, conv3, norm3 = hot
+        edges = ops.DEFER_EDGES
+        out = conv_bn_act(tape, conv1, norm1, x, relu=True,
+                          defer="conv2" in edges, owns_input_grad=self.downsample is None)
+        out = conv_bn_act(tape, conv2, norm2, out, relu=True, tag="k3",
+                          defer="conv3" in edges, owns_input_grad=True)
+        return conv_bn_act(tape, conv3, norm3, out, relu=True, residual=identity,
                            owns_input_grad=True)
 
     def forward(self, x):

@@ -154,6 +154,10 @@ class GradReducer:
 
     def begin(self, params, key=None):
         """Arm the reducer for one backward pass over ``params`` (the active subnet)."""
+        if world_size() == 1:      # nothing to exchange: no plan, no per-parameter hooks
+            self._active = None
+            self._works = []
+            return
         plan = self._plan(params, key)
         pending, owner = [], {}
         for bi, b in enumerate(plan):

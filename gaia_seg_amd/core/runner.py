@@ -181,6 +181,7 @@ class IterBasedRunner:
         self.arch_key = None
         self.arch_meta = None
         self._split_cache = {}
+        self._active_cache = {}
         # GS_HOST_PROF=1: accumulate host-side seconds per phase of train_iter (diagnostics)
         self.host_prof = {} if os.environ.get("GS_HOST_PROF") else None
         # ---- step graphs (see train_iter) ----
@@ -218,14 +219,25 @@ class IterBasedRunner:
             self.arch_key = ("current",)
         self.refresh_active()
 
-    def refresh_active(self):
+    def refresh_active(self, force=False):
         """Recompute the active parameter sets from the model's CURRENT arch state.  Frozen
         parameters (frozen_stages / frozen_layers / norm_cfg requires_grad=False) are left out of
         the zero / all-reduce / SGD ranges: torch.optim.SGD skips parameters without a gradient,
-        so they must neither decay nor move (gaiaseg/models/backbones/dynamic_resnet.py:304-334)."""
-        self.active_params = self.model.active_parameters()
-        self.trainable_params = [p for p in self.active_params if p.requires_grad]
+        so they must neither decay nor move (gaiaseg/models/backbones/dynamic_resnet.py:304-334).
+        The sets of a named / sampled subnet are cached by its arch key (the module walk costs
+        ~0.4 ms per step otherwise); ``force`` drops the cache (requires_grad flags were edited)."""
         key = self.arch_key if self.arch_key != ("current",) else None
+        if force:
+            self._active_cache.clear()
+        hit = self._active_cache.get(key) if key is not None else None
+        if hit is None:
+            active = self.model.active_parameters()
+            hit = (active, [p for p in active if p.requires_grad])
+            if key is not None:
+                if len(self._active_cache) > 1024:
+                    self._active_cache.clear()
+                self._active_cache[key] = hit
+        self.active_params, self.trainable_params = hit
         self.active_ranges = self.arena.ranges_for(self.trainable_params, key)
 
     def split_ranges(self):

@@ -143,10 +143,9 @@ def test_grad_reducer_plan_covers_active_ranges_once():
     plan = red._plan(active, key="k")
     covered = sorted(r for b in plan for r in b["runs"])
     assert covered == [(0, 192), (256, 576)]
-    red.begin(active, "k")
-    for p in reversed(active):
-        p._gs_grad_ready(p)
-    red.finish()                                               # world size 1: nothing to wait for
+    red.begin(active, "k")                                     # world size 1: nothing is armed
+    assert not any(hasattr(p, "_gs_grad_ready") for p in active)
+    red.finish()                                               # ... and nothing to wait for
 
 
 def test_closed_form_flops_match_baseline_table(psp_model):
