@@ -105,8 +105,12 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const CeArgs a, const float
 }
 
 // one block: lanes stride over the partials, fixed-order wave + LDS combine (bit-reproducible)
+// SCALED: out2 = {float(sum loss) * loss_scale, float(#correct) * acc_scale} as fp32 — the rounding
+// order of `out.float() * scale` on the host side, which it replaces (five tiny launches per head)
+template <bool SCALED>
 __global__ __launch_bounds__(256) void ce_final_kernel(const double* __restrict__ part, int nparts,
-                                                       double* out) {
+                                                       double* out, float loss_scale,
+                                                       float acc_scale, float* out2) {
   __shared__ double sh[8];
   double l = 0.0, c = 0.0;
   for (int p = threadIdx.x; p < nparts; p += 256) { l += part[2 * p]; c += part[2 * p + 1]; }
@@ -116,8 +120,14 @@ __global__ __launch_bounds__(256) void ce_final_kernel(const double* __restrict_
   if (lane == 0) { sh[wave] = l; sh[4 + wave] = c; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    out[0] = sh[0] + sh[1] + sh[2] + sh[3];
-    out[1] = sh[4] + sh[5] + sh[6] + sh[7];
+    const double ls = sh[0] + sh[1] + sh[2] + sh[3], cs = sh[4] + sh[5] + sh[6] + sh[7];
+    if (SCALED) {
+      out2[0] = (float)ls * loss_scale;
+      out2[1] = (float)cs * acc_scale;
+    } else {
+      out[0] = ls;
+      out[1] = cs;
+    }
   }
 }
 
@@ -385,7 +395,28 @@ extern "C" int gs_ce_forward(const gs_ce_desc* d, const float* logits, const int
   double* part = static_cast<double*>(workspace);
   hipLaunchKernelGGL(ce_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, a, logits, labels,
                      pixel_weight, class_weight, lse, part, (float*)nullptr);
-  hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(256), 0, st, part, grid, out);
+  hipLaunchKernelGGL(ce_final_kernel<false>, dim3(1), dim3(256), 0, st, part, grid, out, 0.f, 0.f,
+                     (float*)nullptr);
+  return launch_status();
+}
+
+extern "C" int gs_ce_forward_scaled(const gs_ce_desc* d, const float* logits, const int64_t* labels,
+                                    const float* pixel_weight, const float* class_weight,
+                                    float* lse, float loss_scale, float acc_scale, float* out2,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  CeArgs a;
+  int rc = check_ce(d, a);
+  if (rc) return rc;
+  if (!logits || !labels || !out2 || !workspace) return GS_E_NULL;
+  const int grid = ce_grid(d);
+  if ((size_t)grid * 2 * sizeof(double) > workspace_bytes) return GS_E_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 7) return GS_E_ALIGN;
+  hipStream_t st = as_stream(stream);
+  double* part = static_cast<double*>(workspace);
+  hipLaunchKernelGGL(ce_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, a, logits, labels,
+                     pixel_weight, class_weight, lse, part, (float*)nullptr);
+  hipLaunchKernelGGL(ce_final_kernel<true>, dim3(1), dim3(256), 0, st, part, grid,
+                     (double*)nullptr, loss_scale, acc_scale, out2);
   return launch_status();
 }
 

@@ -122,6 +122,7 @@ PROTOTYPES = {
     "gs_scale_nc": (_i32, [_P, _i32, _P, _i32, _i64, _i32, _P, _i32, _P]),
     "gs_ce_workspace_bytes": (_sz, [_CE]),
     "gs_ce_forward": (_i32, [_CE, _P, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "gs_ce_forward_scaled": (_i32, [_CE, _P, _P, _P, _P, _P, _f32, _f32, _P, _P, _sz, _P]),
     "gs_ce_backward": (_i32, [_CE, _P, _P, _P, _P, _P, _f32, _P, _i32, _P]),
     "gs_ce_backward_workspace_bytes": (_sz, [_CE, _i32]),
     "gs_ce_backward_ws": (_i32, [_CE, _P, _P, _P, _P, _P, _f32, _P, _i32, _P, _sz, _P]),

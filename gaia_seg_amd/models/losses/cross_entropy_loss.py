@@ -33,11 +33,13 @@ def _ce_desc(logits, label_hw, ignore_index, align_corners):
 
 
 class _FusedResizeCE(torch.autograd.Function):
-    """(sum_i w_i*ce_i, #correct) of bilinearly resized logits; backward gathers into the
-    low-resolution logits."""
+    """(loss_scale * sum_i w_i*ce_i, acc_scale * #correct) of bilinearly resized logits, both fp32
+    scalars written by the loss kernel's last launch; backward gathers into the low-resolution
+    logits."""
 
     @staticmethod
-    def forward(ctx, logits, label, pixel_weight, class_weight, ignore_index, align_corners):
+    def forward(ctx, logits, label, pixel_weight, class_weight, ignore_index, align_corners,
+                loss_scale, acc_scale):
         require_gpu_tensor(logits, "seg_logit")
         L = _lib.load()
         dev = logits.device
@@ -51,23 +53,23 @@ class _FusedResizeCE(torch.autograd.Function):
         if class_weight is not None:
             class_weight = class_weight.contiguous().float()
         lse = torch.empty((n, hh, ww), dtype=torch.float32, device=dev)
-        out = torch.empty(2, dtype=torch.float64, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
         nb = L.gs_ce_workspace_bytes(ctypes.byref(d))
         ws = WORKSPACE.get(nb, dev)
-        _lib.check(L.gs_ce_forward(ctypes.byref(d), logits.data_ptr(), label.data_ptr(),
-                                   pixel_weight.data_ptr() if pixel_weight is not None else None,
-                                   class_weight.data_ptr() if class_weight is not None else None,
-                                   lse.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                   current_stream_ptr()), "gs_ce_forward")
+        _lib.check(L.gs_ce_forward_scaled(
+            ctypes.byref(d), logits.data_ptr(), label.data_ptr(),
+            pixel_weight.data_ptr() if pixel_weight is not None else None,
+            class_weight.data_ptr() if class_weight is not None else None,
+            lse.data_ptr(), loss_scale, acc_scale, out.data_ptr(), ws.data_ptr(), ws.numel(),
+            current_stream_ptr()), "gs_ce_forward_scaled")
         ctx.desc = d
+        ctx.loss_scale = loss_scale
         ctx.save_for_backward(logits, label, lse)
         ctx.pixel_weight, ctx.class_weight = pixel_weight, class_weight
-        res = out.float()
-        # (elementwise adds, not .clone(): a 4-byte device-to-device hipMemcpyAsync is served by a
-        # chain of ~14 blit launches on ROCm 7.2, r01 trace)
-        loss_sum, correct = res[0] + 0.0, res[1] + 0.0
-        ctx.mark_non_differentiable(correct)
-        return loss_sum, correct
+        # (two views of the kernel's output: no launches; r01 produced them with five tiny kernels)
+        loss, acc = out[0], out[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
 
     @staticmethod
     def backward(ctx, grad_loss, grad_acc):
@@ -83,12 +85,12 @@ class _FusedResizeCE(torch.autograd.Function):
         _lib.check(L.gs_ce_backward_ws(ctypes.byref(d), logits.data_ptr(), label.data_ptr(),
                                        pw.data_ptr() if pw is not None else None,
                                        cw.data_ptr() if cw is not None else None, lse.data_ptr(),
-                                       1.0, buf.data_ptr(), ld, ws.data_ptr(), ws.numel(),
+                                       ctx.loss_scale, buf.data_ptr(), ld, ws.data_ptr(), ws.numel(),
                                        current_stream_ptr()), "gs_ce_backward_ws")
         # scale by the upstream scalar on device (no host sync); the tensor is low resolution
         buf.mul_(grad_loss)
         dlogits = buf[..., :c].permute(0, 3, 1, 2)
-        return dlogits, None, None, None, None, None
+        return dlogits, None, None, None, None, None, None, None
 
 
 def seg_loss_and_accuracy(seg_logit, seg_label, weight=None, class_weight=None, ignore_index=255,
@@ -97,10 +99,9 @@ def seg_loss_and_accuracy(seg_logit, seg_label, weight=None, class_weight=None, 
     loss = loss_weight * sum_i(w_i * ce_i) / label.numel();  acc = 100 * correct / label.numel()."""
     if seg_label.dim() == 4:
         seg_label = seg_label.squeeze(1)
-    s, correct = _FusedResizeCE.apply(seg_logit, seg_label, weight, class_weight, ignore_index,
-                                      align_corners)
     numel = seg_label.numel()
-    return s * (loss_weight / numel), correct * (100.0 / numel)
+    return _FusedResizeCE.apply(seg_logit, seg_label, weight, class_weight, ignore_index,
+                                align_corners, loss_weight / numel, 100.0 / numel)
 
 
 @LOSSES.register_module()

@@ -232,12 +232,16 @@ class EncoderDecoder(nn.Module):
         log_vars = OrderedDict()
         for loss_name, loss_value in losses.items():
             if isinstance(loss_value, torch.Tensor):
-                log_vars[loss_name] = loss_value.mean()
+                # (the heads return scalars: their mean is themselves, without a reduce launch)
+                log_vars[loss_name] = loss_value if loss_value.dim() == 0 else loss_value.mean()
             elif isinstance(loss_value, list):
                 log_vars[loss_name] = sum(_loss.mean() for _loss in loss_value)
             else:
                 raise TypeError("%s is not a tensor or list of tensors" % loss_name)
-        loss = sum(_value for _key, _value in log_vars.items() if "loss" in _key)
+        parts = [_value for _key, _value in log_vars.items() if "loss" in _key]
+        loss = parts[0]
+        for _value in parts[1:]:   # (sum() would start from the integer 0: one more launch)
+            loss = loss + _value
         log_vars["loss"] = loss
         # one batched all-reduce for all log scalars instead of one per entry; values are kept on
         # the device (no host sync inside the step) — loggers call .item() when they print

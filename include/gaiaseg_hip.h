@@ -338,6 +338,13 @@ size_t gs_ce_workspace_bytes(const gs_ce_desc* d);
 int gs_ce_forward(const gs_ce_desc* d, const float* logits, const int64_t* labels,
                   const float* pixel_weight, const float* class_weight, float* lse, double* out,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* Same, with the host-side epilogue of `losses` folded in: out2[0] = float(out[0]) * loss_scale
+ * (= loss_weight / (N*H*W)), out2[1] = float(out[1]) * acc_scale (= 100 / (N*H*W)), both fp32 —
+ * dynamic_fcn_head.py:149-159 computes exactly these two scalars. */
+int gs_ce_forward_scaled(const gs_ce_desc* d, const float* logits, const int64_t* labels,
+                         const float* pixel_weight, const float* class_weight, float* lse,
+                         float loss_scale, float acc_scale, float* out2, void* workspace,
+                         size_t workspace_bytes, void* stream);
 /* dlogits[n,y,x,c] = grad_scale * sum_p bilinear_w(p->(y,x)) * w_p * cw * (softmax_p[c] - [c==label_p])
  * written densely (pixel stride ld_d, columns Cls..ld_d-1 zeroed).  Deterministic gather form:
  * one workgroup per low-resolution logit pixel walks its bilinear footprint. */
