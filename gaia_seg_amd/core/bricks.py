@@ -68,6 +68,8 @@ def relayout_conv_params(conv):
         view.copy_(w.data)
         w.data = view
         w.grad = None
+    w.__dict__.pop("_gs_plans", None)   # cached launch plans (hip/ops.py) describe the old storage
+    conv.__dict__.pop("_layout_ptr", None)
     w._gs_phys_shape = (kh, kw, ci, co_ld)
     w._gs_grad_factory = lambda w=w, co=co, shape=(kh, kw, ci, co_ld): hwio_logical_view(
         torch.zeros(shape, dtype=w.dtype, device=w.device), co)
