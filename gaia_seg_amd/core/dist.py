@@ -22,6 +22,7 @@ The same code runs over gloo on CPU tensors, which is how the multi-process test
 """
 import torch
 import torch.distributed as dist
+_coalescing_manager = getattr(dist, "_coalescing_manager", None)   # (private in torch 2.x; optional)
 
 
 def is_dist():
@@ -207,11 +208,20 @@ class GradReducer:
             self._issue(runs)
 
     def _issue(self, runs):
-        for a, b in runs:
-            t = self.flat_grad[a:b]
+        """All-reduce one bucket.  A bucket is one arena range unless depth-skipped blocks left
+        holes in it; its runs then go out as ONE grouped collective (ncclGroupStart/End on RCCL,
+        allreduce_coalesced on gloo) instead of one launch per run."""
+        tensors = [self.flat_grad[a:b] for a, b in runs]
+        self.bytes_reduced += sum(t.numel() * t.element_size() for t in tensors)
+        if len(tensors) > 1 and _coalescing_manager is not None:
+            with _coalescing_manager(self.group, async_ops=True) as cm:
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._works.append(cm)
+            return
+        for t in tensors:
             self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
-            self.bytes_reduced += t.numel() * t.element_size()
 
     def finish(self):
         """Flush buckets whose parameters never reported (no gradient this step) and wait."""
