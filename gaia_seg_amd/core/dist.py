@@ -22,7 +22,6 @@ The same code runs over gloo on CPU tensors, which is how the multi-process test
 """
 import torch
 import torch.distributed as dist
-_coalescing_manager = getattr(dist, "_coalescing_manager", None)   # (private in torch 2.x; optional)
 
 
 def is_dist():
@@ -208,20 +207,15 @@ class GradReducer:
             self._issue(runs)
 
     def _issue(self, runs):
-        """All-reduce one bucket.  A bucket is one arena range unless depth-skipped blocks left
-        holes in it; its runs then go out as ONE grouped collective (ncclGroupStart/End on RCCL,
-        allreduce_coalesced on gloo) instead of one launch per run."""
-        tensors = [self.flat_grad[a:b] for a, b in runs]
-        self.bytes_reduced += sum(t.numel() * t.element_size() for t in tensors)
-        if len(tensors) > 1 and _coalescing_manager is not None:
-            with _coalescing_manager(self.group, async_ops=True) as cm:
-                for t in tensors:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            self._works.append(cm)
-            return
-        for t in tensors:
+        """All-reduce one bucket: one call per contiguous run (a bucket is a single arena range
+        unless depth-skipped blocks left holes in it).  Grouping the runs into one coalesced call
+        was tried (torch's private _coalescing_manager): gloo cannot coalesce device tensors, and an
+        RCCL-only branch could not be exercised on a one-GPU box, so the tested form stays."""
+        for a, b in runs:
+            t = self.flat_grad[a:b]
             self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
+            self.bytes_reduced += t.numel() * t.element_size()
 
     def finish(self):
         """Flush buckets whose parameters never reported (no gradient this step) and wait."""

@@ -50,7 +50,7 @@ def _worker_reducer(rank, world, port, q):
         o, n = segs[id(params[i])]
         want[o:o + n] = sum(b[o:o + n] for b in both)
     ok = bool(torch.allclose(flat, want))
-    # one large bucket: its three runs (holes at the skipped blocks) travel as ONE grouped collective
+    # one large bucket with holes at the skipped blocks: three runs, three calls, same result
     flat.copy_(local)
     red2 = GradReducer(flat, segs, bucket_bytes=4 * 4000)
     plan = red2._plan(active, key=("arch", 2))
