@@ -371,7 +371,9 @@ def main():
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
+    seg0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
     elapsed = timed_pass(False)                      # <- `value`: nothing but the training steps
+    seg_new = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0) - seg0
     if prof is not None:
         prof.disable()
         import pstats
@@ -431,6 +433,7 @@ def main():
                 "parallelism": "dp%d" % world,
                 "allreduce_bytes_per_step_per_rank": int(bytes_per_step),
                 "last_loss": round(loss, 5),
+                "device_mallocs_in_timed_steps": int(seg_new),
                 "step_graphs": dict(runner.graph_stats, built_at_startup=graphs_built,
                                     what="HIP-graph replay of recurring subnets' whole training "
                                          "step (same kernels as the eager step); counts cover "

@@ -92,7 +92,7 @@ class Act:
         # ops.materialize() writes it out.  ``g`` is always the gradient of the logical value.
         self.affine = None
         # Cross-layer fusion of the BatchNorm backward reduction (ops.conv_bn): ``bnb`` = (y Act,
-        # coefficient tensor, mask mode, post-activation Act or None) describes the BN + ReLU that
+        # coefficient tensor, mask mode) describes the BN + ReLU that
         # produced this activation; a consumer whose data gradient is the last contribution to ``g``
         # may fold that BN's reduction into its dgrad epilogue and leaves the sums in ``bnb_sums``.
         self.bnb = None
