@@ -140,6 +140,18 @@ def _L():
     return _lib.load()
 
 
+_INT32_ARRAYS = {}
+
+
+def _int32_array(n):
+    """ctypes array type of n int32 (cached: creating the type per call leaves a cycle of type
+    objects for the garbage collector at every step)."""
+    t = _INT32_ARRAYS.get(n)
+    if t is None:
+        t = _INT32_ARRAYS[n] = ctypes.c_int32 * n
+    return t
+
+
 def ensure_grad(param):
     """``param.grad`` with the physical layout of ``param`` (zeros on first use).
 
@@ -806,7 +818,7 @@ def adaptive_avgpool(tape, x, scales):
     L = _L()
     dev = x.t.device
     ns = len(scales)
-    arr = (ctypes.c_int32 * ns)(*scales)
+    arr = _int32_array(ns)(*scales)
     total_bins = sum(s * s for s in scales)
     ybuf = torch.empty(x.N * total_bins * x.C, dtype=torch.float32, device=dev)
     nb = L.gs_adaptive_avgpool_workspace_bytes(x.N, x.H, x.W, x.C, arr, ns)

@@ -47,7 +47,8 @@ def main():
     cel.require_gpu_tensor = lambda t, what: None
     cel.current_stream_ptr = lambda: 0
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg = Config.fromfile(os.path.join(root, "configs/supernet/fcn_ar50to101v2.py"))
+    name = next((a for a in sys.argv[1:] if a.endswith(".py")), "configs/supernet/fcn_ar50to101v2.py")
+    cfg = Config.fromfile(os.path.join(root, name))
     torch.manual_seed(0)
     model = build_segmentor(cfg.model, train_cfg=cfg.get("train_cfg"),
                             test_cfg=cfg.get("test_cfg")).train()

@@ -242,8 +242,10 @@ def test_training_step_leaves_no_reference_cycles():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    res = subprocess.run([sys.executable, os.path.join(here, "host_dry_run.py"), "2"],
-                         capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    out = json.loads(res.stdout.strip().splitlines()[-1])
-    assert out["unreachable_per_step"] == 0, out
+    for cfg in ("fcn", "pspnet", "upernet"):
+        res = subprocess.run([sys.executable, os.path.join(here, "host_dry_run.py"), "2",
+                              "configs/supernet/%s_ar50to101v2.py" % cfg],
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out = json.loads(res.stdout.strip().splitlines()[-1])
+        assert out["unreachable_per_step"] == 0, (cfg, out)
