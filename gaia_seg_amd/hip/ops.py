@@ -47,6 +47,9 @@ WGRAD_BATCH = max(1, int(os.environ.get("GS_WGRAD_BATCH", "4")))
 _wgrad_jobs = []
 
 
+_side_keep = []   # (dy, x) of weight-gradient kernels launched on the side stream, until the join
+
+
 def queue_wgrad(d, x, dy, weight, gw, need, dev):
     """x: Act (kept alive until the launch), dy: gradient of the conv output, gw: weight.grad."""
     _wgrad_jobs.append((d, x, dy, weight, gw, need, dev))
@@ -67,8 +70,11 @@ def flush_wgrads():
         _lib.check(L.gs_stream_fork(current_stream_ptr(), side.cuda_stream), "gs_stream_fork")
         for d, x, dy, weight, gw, need, _ in jobs:
             ws_s = _side_workspace(need, dev, side)
-            dy.record_stream(side)
-            x.t.record_stream(side)
+            # dy and x must outlive the side-stream kernel that reads them: they are kept referenced
+            # until the main stream has joined the side stream (join_side_streams) instead of being
+            # handed to the caching allocator with record_stream (two calls and one pending event
+            # per convolution and step)
+            _side_keep.append((dy, x))
             # (descriptors are shared per layer: the operand-loader coefficients are per call)
             d.in_affine = x.affine.data_ptr() if x.affine is not None else None
             _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
@@ -107,6 +113,10 @@ def join_side_streams(dev=None):
             with torch.cuda.device(s.device):
                 _lib.check(_L().gs_stream_fork(s.cuda_stream, current_stream_ptr()), "gs_stream_fork")
             _side_dirty[key] = False
+    if dev is None or not any(_side_dirty.values()):
+        # everything the side stream read is now ordered before whatever the current stream does
+        # next: the operands may go back to the allocator
+        _side_keep.clear()
 
 
 def side_stream_after_main(dev):
