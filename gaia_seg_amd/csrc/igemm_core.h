@@ -737,6 +737,129 @@ __device__ __forceinline__ void pipelined_k_loop_pairs(
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16x3 K loop (experimental, GS_X3=<min K steps>): the fp32 contraction as SIX bf16 MFMAs over an
+// exact three-way bf16 split of both operands (x = x0 + x1 + x2 with 8 mantissa bits each; products
+// a_i * b_j for i + j <= 2, smallest first, fp32 accumulation in v_mfma_f32_16x16x32_bf16): as
+// accurate as the fp32 MFMA against fp64 (profiles/r02_bf16x3_probe.md) at 6 x 16 instead of
+// 8 x 32 MFMA cycles per 16x16x32 of work.  One step = TWO 16-channel K steps of the loaders (the
+// thread that stages (row, kq) holds channels 4kq..4kq+3 of both: its 8 values are one 16-byte bf16
+// chunk per piece; any k order works as long as both operands use it).  Operands are split ONCE,
+// at the stage store; LDS holds [piece][row][32 bf16 + 16 B pad] (80-byte rows: conflict-free
+// 16-byte fragment reads).  Both operands must be k-contiguous per row: dgrad (BTRANS) only.
+// Global loads run four steps ahead of the MFMAs (four register sets), the split + stage store
+// one step ahead (two LDS stages, one barrier per step).
+// ------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ u32x4 x3_pack(const u32x4 a, const u32x4 b) {
+  return u32x4{(a[0] >> 16) | (a[1] & 0xFFFF0000u), (a[2] >> 16) | (a[3] & 0xFFFF0000u),
+               (b[0] >> 16) | (b[1] & 0xFFFF0000u), (b[2] >> 16) | (b[3] & 0xFFFF0000u)};
+}
+__device__ __forceinline__ void x3_split(const f32x4 lo4, const f32x4 hi4, u32x4& p0, u32x4& p1,
+                                         u32x4& p2) {
+  const u32x4 mask{0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u};
+  const u32x4 hl = __builtin_bit_cast(u32x4, lo4) & mask, hh = __builtin_bit_cast(u32x4, hi4) & mask;
+  const f32x4 r1l = lo4 - __builtin_bit_cast(f32x4, hl), r1h = hi4 - __builtin_bit_cast(f32x4, hh);
+  const u32x4 ml = __builtin_bit_cast(u32x4, r1l) & mask, mh = __builtin_bit_cast(u32x4, r1h) & mask;
+  const f32x4 r2l = r1l - __builtin_bit_cast(f32x4, ml), r2h = r1h - __builtin_bit_cast(f32x4, mh);
+  p0 = x3_pack(hl, hh);
+  p1 = x3_pack(ml, mh);
+  p2 = x3_pack(__builtin_bit_cast(u32x4, r2l), __builtin_bit_cast(u32x4, r2h));
+}
+
+template <int BN>
+struct X3Tile {
+  static constexpr int ROWB = 80;
+  static constexpr int PA = 64 * ROWB, PB = BN * ROWB;
+  static constexpr int STAGE = 3 * PA + 3 * PB;            // bytes
+  static constexpr int LDS_FLOATS = 2 * STAGE / 4;
+};
+
+template <int BM, int BN, int AS, class LA, class LB>
+__device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
+                                          f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN],
+                                          int wave, int lane, int t, LA&& load_a, LB&& load_b) {
+  using T = Tile<BM, BN>;
+  using X = X3Tile<BN>;
+  using G = ColGroups<T::TN>;
+  static_assert(BM == 64 && AS == 1 && T::BV == 1, "bf16x3 loop: 64-row tiles, BN <= 64");
+  unsigned char* lds = reinterpret_cast<unsigned char*>(ldsf);
+  const int li = lane & 15, fk = lane >> 4;
+  const int row = t >> 2, kq = t & 3;
+  const bool b_on = t < BK * BN / 4;   // B rows 0..BN-1 (four staging threads each)
+  // register sets: step k lives in set k % 4
+  f32x4 a0[4][AS], a1[4][AS], b0[4][T::BV], b1[4][T::BV];
+  auto gload = [&](int set) __attribute__((always_inline)) {
+    load_a(a0[set]); load_b(b0[set]);     // (load_b advances the K state)
+    load_a(a1[set]); load_b(b1[set]);
+  };
+  auto sstore = [&](int set, unsigned char* st) __attribute__((always_inline)) {
+    u32x4 p0, p1, p2;
+    x3_split(a0[set][0], a1[set][0], p0, p1, p2);
+    unsigned char* pa = st + row * X::ROWB + kq * 16;
+    *reinterpret_cast<u32x4*>(pa) = p0;
+    *reinterpret_cast<u32x4*>(pa + X::PA) = p1;
+    *reinterpret_cast<u32x4*>(pa + 2 * X::PA) = p2;
+    if (b_on) {
+      x3_split(b0[set][0], b1[set][0], p0, p1, p2);
+      unsigned char* pb = st + 3 * X::PA + row * X::ROWB + kq * 16;
+      *reinterpret_cast<u32x4*>(pb) = p0;
+      *reinterpret_cast<u32x4*>(pb + X::PB) = p1;
+      *reinterpret_cast<u32x4*>(pb + 2 * X::PB) = p2;
+    }
+  };
+  // B fragment row of MFMA block j for this lane: the column the epilogue expects there
+  int brow[T::TN];
+#pragma unroll
+  for (int j = 0; j < T::TN; ++j) brow[j] = G::base(j) + G::width(j) * li + (j - G::first(j));
+  auto compute = [&](const unsigned char* cb) __attribute__((always_inline)) {
+    bf16x8 fa[3], fb[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      fa[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+          cb + p * X::PA + (wave * 16 + li) * X::ROWB + fk * 16));
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        fb[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+            cb + 3 * X::PA + p * X::PB + brow[j] * X::ROWB + fk * 16));
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1], acc[0][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0], acc[0][j], 0, 0, 0);
+    }
+  };
+  const int nst = (nk16 + 1) >> 1;
+  if (nst <= 0) return;
+  unsigned char* buf0 = lds;
+  unsigned char* buf1 = lds + X::STAGE;
+  // (loads past the K range return zeros: the loaders' kvalid test, so the prologue needs no guard)
+  gload(0); gload(1); gload(2); gload(3);
+  sstore(0, buf0);
+  __syncthreads();
+  // phase i (set = i % 4): compute step i from cur, refill set i % 4 with step i + 4, store step
+  // i + 1 (set (i + 1) % 4, loaded three phases ago) into the other stage
+#define GS_X3_PHASE(I, CUR, NXT)                                  \
+  if (s + (I) < nst) {                                             \
+    gload((I) & 3);                                                \
+    compute(CUR);                                                  \
+    sstore(((I) + 1) & 3, NXT);                                    \
+    __syncthreads();                                               \
+  }
+  for (int s = 0; s < nst; s += 4) {
+    GS_X3_PHASE(0, buf0, buf1)
+    GS_X3_PHASE(1, buf1, buf0)
+    GS_X3_PHASE(2, buf0, buf1)
+    GS_X3_PHASE(3, buf1, buf0)
+  }
+#undef GS_X3_PHASE
+}
+
+// ------------------------------------------------------------------------------------------
 // Fast path of forward / stride-1 dgrad for the shapes that carry the FLOPs: NHWC source,
 // channels per tap a multiple of BK (every width of the search space is a multiple of 16), 1x1 or
 // 3x3.  Versus the general kernel above:
@@ -764,10 +887,12 @@ __device__ __forceinline__ unsigned long long gs_stamp() {
 // global loads are issued, two K steps before they are needed) and the tap-validity bits, so the
 // affine + ReLU + zero-padding select run in the store slot on values that are already there.
 template <int BM, int BN, bool BTRANS, int KS, int ABL = 0, int ROLE = 0, bool PIPE = true,
-          bool PAIR = false, bool AFF = false>
+          bool PAIR = false, bool AFF = false, bool X3 = false>
 __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
-  constexpr int LDS_TILES = PAIR ? T::LDSF2 : T::LDSF;
+  static_assert(!X3 || (BTRANS && PIPE && !PAIR && !AFF && ABL == 0), "bf16x3 loop: dgrad only");
+  constexpr int LDS_X3 = X3Tile<BN>::LDS_FLOATS > T::C_SZ + 512 ? X3Tile<BN>::LDS_FLOATS : T::C_SZ + 512;
+  constexpr int LDS_TILES = X3 ? LDS_X3 : (PAIR ? T::LDSF2 : T::LDSF);
   __shared__ __attribute__((aligned(16))) float lds[LDS_TILES + (AFF ? 3 * kAffMaxC : 0)];
   constexpr int AS = BM / 64;
   constexpr int AX = AFF ? AS + 4 : AS;   // register-set size handed to the pipelined loop
@@ -1023,7 +1148,9 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
       }
     };
     GS_STAMP(st_l0)
-    if constexpr (PAIR)
+    if constexpr (X3)
+      x3_k_loop<BM, BN, AX>(nk, lds, acc, wave, lane, t, load_a, load_b);
+    else if constexpr (PAIR)
       pipelined_k_loop_pairs<BM, BN, AX>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
     else
       pipelined_k_loop<BM, BN, AX>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
@@ -1647,6 +1774,20 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
   // their fill / drain (r01 A/B: s2..s4 3x3 and the head convs +3..7 %, s1 3x3 -3 % if paired)
   const bool pair = pl.nk_per_split >= pair_min_ksteps() &&
                     (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
+  if constexpr (BTRANS) {
+    // experimental bf16x3 contraction (see x3_k_loop): stride-1 dgrad, 64-row tiles, BN 64 / 48
+    static const int x3_min = env_int("GS_X3", 0);   // 0 = off, else the minimum K steps per workgroup
+    if (x3_min > 0 && pl.bm == 64 && pl.nk_per_split >= x3_min) {
+      if (pl.bn == 64) {
+        hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, true, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
+        return;
+      }
+      if (pl.bn == 48) {
+        hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 48, true, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
+        return;
+      }
+    }
+  }
   if constexpr (!BTRANS) {
     if (a.a_coeffs) {   // relu(bn(x)) evaluated in the loader: 64-row tiles (the planner's choice)
 #define GS_FAST_AFF(BN_)                                                                   \
