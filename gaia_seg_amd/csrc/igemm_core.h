@@ -768,12 +768,16 @@ __device__ __forceinline__ void x3_split(const f32x4 lo4, const f32x4 hi4, u32x4
   p2 = x3_pack(__builtin_bit_cast(u32x4, r2l), __builtin_bit_cast(u32x4, r2h));
 }
 
+// one LDS stage (two barriers per step, three workgroups per CU by registers) or two (one barrier,
+// two workgroups per CU by LDS)
+constexpr int kX3Stages = 1;
+
 template <int BN>
 struct X3Tile {
   static constexpr int ROWB = 80;
   static constexpr int PA = 64 * ROWB, PB = BN * ROWB;
   static constexpr int STAGE = 3 * PA + 3 * PB;            // bytes
-  static constexpr int LDS_FLOATS = 2 * STAGE / 4;
+  static constexpr int LDS_FLOATS = kX3Stages * STAGE / 4;
 };
 
 template <int BM, int BN, int AS, class LA, class LB>
@@ -836,7 +840,7 @@ __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
   const int nst = (nk16 + 1) >> 1;
   if (nst <= 0) return;
   unsigned char* buf0 = lds;
-  unsigned char* buf1 = lds + X::STAGE;
+  unsigned char* buf1 = kX3Stages == 2 ? lds + X::STAGE : lds;
   // (loads past the K range return zeros: the loaders' kvalid test, so the prologue needs no guard)
   gload(0); gload(1); gload(2); gload(3);
   sstore(0, buf0);
@@ -847,6 +851,7 @@ __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
   if (s + (I) < nst) {                                             \
     gload((I) & 3);                                                \
     compute(CUR);                                                  \
+    if (kX3Stages == 1) __syncthreads();                           \
     sstore(((I) + 1) & 3, NXT);                                    \
     __syncthreads();                                               \
   }
