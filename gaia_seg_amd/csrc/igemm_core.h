@@ -199,12 +199,25 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const f
 // Accumulators -> LDS (column chunk `ch`) in [row][col] order.  C/D map of the 16x16 MFMA:
 // row = (lane >> 4) * 4 + reg, column inside block j = lane & 15, i.e. (ColGroups) global column
 // base(j) + width(j) * (lane & 15) + (j - first(j)): one vector store per group and register.
-template <int BM, int BN>
+// QUAD (bf16x3 loop, 64x64 tiles): the four accumulator blocks of a wave are a 2 x 2 arrangement
+// inside the wave's 32 x 32 quadrant of the tile (wave = 2 * row half + column half; block q = 2 *
+// row block + column block) instead of a 16 x 64 stripe.
+template <int BM, int BN, bool QUAD = false>
 __device__ __forceinline__ void acc_to_lds(float* __restrict__ Cs,
                                            const f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN],
                                            int ch, int wave, int lane) {
   using T = Tile<BM, BN>;
   using G = ColGroups<T::TN>;
+  if constexpr (QUAD) {
+    static_assert(BM == 64 && BN == 64, "quadrant layout: 64x64 tiles");
+    const int r0 = (wave >> 1) * 32 + (lane >> 4) * 4, c0 = (wave & 1) * 32 + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cs[(r0 + (q >> 1) * 16 + r) * T::PC + c0 + (q & 1) * 16] = acc[0][q][r];
+    return;
+  }
   constexpr int TPC = T::CCH / 16;  // 16-col blocks per chunk
   const int li = lane & 15;
 #pragma unroll
@@ -429,7 +442,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
 }
 
 // Shared epilogue of the row kernels: accumulators -> LDS -> coalesced float4 rows.
-template <int BM, int BN>
+template <int BM, int BN, bool QUAD = false>
 __device__ __forceinline__ void rows_epilogue(
     const IgemmArgs& p, float* lds, const f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN], int m0,
     int n0, int t, int wave, int lane, int split) {
@@ -446,7 +459,7 @@ __device__ __forceinline__ void rows_epilogue(
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       if (ch > 0) __syncthreads();
-      acc_to_lds<BM, BN>(Cs, acc, ch, wave, lane);
+      acc_to_lds<BM, BN, QUAD>(Cs, acc, ch, wave, lane);
       __syncthreads();
       const int col = n0 + ch * T::CCH + q * 4;
       const bool cv = q * 4 < T::CCH && ch * T::CCH + q * 4 < BN && col < p.Nn;
@@ -495,7 +508,7 @@ __device__ __forceinline__ void rows_epilogue(
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     if (ch > 0) __syncthreads();
-    acc_to_lds<BM, BN>(Cs, acc, ch, wave, lane);
+    acc_to_lds<BM, BN, QUAD>(Cs, acc, ch, wave, lane);
     __syncthreads();
     constexpr int QPR = T::CCH / 4;
     for (int idx = t; idx < BM * QPR; idx += NT) {
@@ -813,11 +826,36 @@ __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
       *reinterpret_cast<u32x4*>(pb + 2 * X::PB) = p2;
     }
   };
+  constexpr bool QUAD = BN == 64;   // 2 x 2 waves of 32 x 32: each wave re-reads half of B, not all
   // B fragment row of MFMA block j for this lane: the column the epilogue expects there
   int brow[T::TN];
 #pragma unroll
   for (int j = 0; j < T::TN; ++j) brow[j] = G::base(j) + G::width(j) * li + (j - G::first(j));
   auto compute = [&](const unsigned char* cb) __attribute__((always_inline)) {
+    if constexpr (QUAD) {
+      bf16x8 qa[2][3], qb[2][3];
+      const int ar = (wave >> 1) * 32 + li, bc = (wave & 1) * 32 + li;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          qa[h][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+              cb + p * X::PA + (ar + h * 16) * X::ROWB + fk * 16));
+          qb[h][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+              cb + 3 * X::PA + p * X::PB + (bc + h * 16) * X::ROWB + fk * 16));
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i2 = q >> 1, j2 = q & 1;
+        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][2], qb[j2][0], acc[0][q], 0, 0, 0);
+        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][1], qb[j2][1], acc[0][q], 0, 0, 0);
+        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][0], qb[j2][2], acc[0][q], 0, 0, 0);
+        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][1], qb[j2][0], acc[0][q], 0, 0, 0);
+        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][0], qb[j2][1], acc[0][q], 0, 0, 0);
+        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][0], qb[j2][0], acc[0][q], 0, 0, 0);
+      }
+      return;
+    }
     bf16x8 fa[3], fb[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -1208,7 +1246,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
       o[4] = d_load; o[5] = d_mfma; o[6] = d_store; o[7] = d_bar;
     }
   } else {
-    rows_epilogue<BM, BN>(p, lds, acc, m0, n0, t, wave, lane, split);
+    rows_epilogue<BM, BN, (X3 && BN == 64)>(p, lds, acc, m0, n0, t, wave, lane, split);
   }
 #undef GS_STAMP
 }
