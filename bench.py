@@ -434,6 +434,9 @@ def main():
                 "allreduce_bytes_per_step_per_rank": int(bytes_per_step),
                 "last_loss": round(loss, 5),
                 "device_mallocs_in_timed_steps": int(seg_new),
+                "contraction": "fp32 MFMA (forward, weight gradient); data gradient: six bf16 MFMAs "
+                               "over an exact three-way bf16 split of both operands, fp32 "
+                               "accumulation (error vs fp64 as the fp32 MFMA; GS_X3=0 turns it off)",
                 "step_graphs": dict(runner.graph_stats, built_at_startup=graphs_built,
                                     what="HIP-graph replay of recurring subnets' whole training "
                                          "step (same kernels as the eager step); counts cover "

@@ -784,6 +784,7 @@ __device__ __forceinline__ void x3_split(const f32x4 lo4, const f32x4 hi4, u32x4
 // one LDS stage (two barriers per step, three workgroups per CU by registers) or two (one barrier,
 // two workgroups per CU by LDS)
 constexpr int kX3Stages = 1;
+constexpr int kX3Sets = 2;     // register sets = how many steps the global loads run ahead
 
 template <int BN>
 struct X3Tile {
@@ -805,8 +806,8 @@ __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
   const int li = lane & 15, fk = lane >> 4;
   const int row = t >> 2, kq = t & 3;
   const bool b_on = t < BK * BN / 4;   // B rows 0..BN-1 (four staging threads each)
-  // register sets: step k lives in set k % 4
-  f32x4 a0[4][AS], a1[4][AS], b0[4][T::BV], b1[4][T::BV];
+  // register sets: step k lives in set k % kX3Sets
+  f32x4 a0[kX3Sets][AS], a1[kX3Sets][AS], b0[kX3Sets][T::BV], b1[kX3Sets][T::BV];
   auto gload = [&](int set) __attribute__((always_inline)) {
     load_a(a0[set]); load_b(b0[set]);     // (load_b advances the K state)
     load_a(a1[set]); load_b(b1[set]);
@@ -880,24 +881,26 @@ __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
   unsigned char* buf0 = lds;
   unsigned char* buf1 = kX3Stages == 2 ? lds + X::STAGE : lds;
   // (loads past the K range return zeros: the loaders' kvalid test, so the prologue needs no guard)
-  gload(0); gload(1); gload(2); gload(3);
+#pragma unroll
+  for (int u = 0; u < kX3Sets; ++u) gload(u);
   sstore(0, buf0);
   __syncthreads();
-  // phase i (set = i % 4): compute step i from cur, refill set i % 4 with step i + 4, store step
-  // i + 1 (set (i + 1) % 4, loaded three phases ago) into the other stage
+  // phase i (set = i % kX3Sets): compute step i from cur, refill its set with step i + kX3Sets,
+  // store step i + 1 (the next set, loaded kX3Sets - 1 phases ago) into the (other) stage
 #define GS_X3_PHASE(I, CUR, NXT)                                  \
   if (s + (I) < nst) {                                             \
-    gload((I) & 3);                                                \
+    gload((I) % kX3Sets);                                          \
     compute(CUR);                                                  \
     if (kX3Stages == 1) __syncthreads();                           \
-    sstore(((I) + 1) & 3, NXT);                                    \
+    sstore(((I) + 1) % kX3Sets, NXT);                              \
     __syncthreads();                                               \
   }
-  for (int s = 0; s < nst; s += 4) {
-    GS_X3_PHASE(0, buf0, buf1)
-    GS_X3_PHASE(1, buf1, buf0)
-    GS_X3_PHASE(2, buf0, buf1)
-    GS_X3_PHASE(3, buf1, buf0)
+  static_assert(12 % kX3Sets == 0 && kX3Sets >= 2, "the phase loop is unrolled by 12");
+  for (int s = 0; s < nst; s += 12) {
+    GS_X3_PHASE(0, buf0, buf1) GS_X3_PHASE(1, buf1, buf0) GS_X3_PHASE(2, buf0, buf1)
+    GS_X3_PHASE(3, buf1, buf0) GS_X3_PHASE(4, buf0, buf1) GS_X3_PHASE(5, buf1, buf0)
+    GS_X3_PHASE(6, buf0, buf1) GS_X3_PHASE(7, buf1, buf0) GS_X3_PHASE(8, buf0, buf1)
+    GS_X3_PHASE(9, buf1, buf0) GS_X3_PHASE(10, buf0, buf1) GS_X3_PHASE(11, buf1, buf0)
   }
 #undef GS_X3_PHASE
 }
@@ -1818,9 +1821,15 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
   const bool pair = pl.nk_per_split >= pair_min_ksteps() &&
                     (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
   if constexpr (BTRANS) {
-    // experimental bf16x3 contraction (see x3_k_loop): stride-1 dgrad, 64-row tiles, BN 64 / 48
-    static const int x3_min = env_int("GS_X3", 0);   // 0 = off, else the minimum K steps per workgroup
-    if (x3_min > 0 && pl.bm == 64 && pl.nk_per_split >= x3_min) {
+    // bf16x3 contraction (see x3_k_loop): stride-1 dgrad, 64-row tiles, BN 64 / 48.  r02 sweep over
+    // the supernet's data-gradient shapes (profiles/r02_bf16x3_probe.md): +7.5 % in sum against the
+    // fp32 loop, ahead everywhere except short split-K ranges (a split's 16 K steps are 8 bf16
+    // steps: the fill does not amortise), which keep the fp32 loop.  GS_X3=0 switches it off,
+    // GS_X3=n (n > 1) raises the minimum K steps per workgroup.
+    static const int x3_min = env_int("GS_X3", 1);
+    const bool x3_ok = x3_min > 0 && pl.bm == 64 && pl.nk_per_split >= x3_min &&
+                       (pl.splits == 1 || pl.nk_per_split >= 32);
+    if (x3_ok) {
       if (pl.bn == 64) {
         hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, true, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
         return;
