@@ -618,14 +618,15 @@ def test_bn_backward_reduction_in_dgrad_epilogue(hip_lib, shape, monkeypatch):
         assert rel_err(a, b) < 2e-5
 
 
-def test_bf16x3_dgrad_loop_parity(hip_lib):
-    """The experimental bf16x3 K loop (GS_X3, csrc/igemm_core.h x3_k_loop: fp32 contraction from six
-    bf16 MFMAs over an exact three-way split) must pass the same data-gradient parity cases as the
-    fp32 loop.  The switch is read once per process, so the cases run in a child interpreter."""
+def test_fp32_dgrad_loop_parity(hip_lib):
+    """The data gradient runs on the bf16x3 K loop by default (csrc/igemm_core.h x3_k_loop: fp32
+    contraction from six bf16 MFMAs over an exact three-way split), so every dgrad case of this file
+    exercises it; GS_X3=0 falls back to the fp32 MFMA loop, which must keep passing the same cases.
+    The switch is read once per process, so they run in a child interpreter."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, GS_X3="2")
+    env = dict(os.environ, GS_X3="0")
     here = os.path.dirname(os.path.abspath(__file__))
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_ops_gpu.py"), "-q",
                           "-x", "-k", "dyn_conv2d_fwd_bwd or conv_bn_fused or deferred"],
