@@ -797,7 +797,8 @@ struct X3Tile {
 template <int BM, int BN, int AS, class LA, class LB>
 __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
                                           f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN],
-                                          int wave, int lane, int t, LA&& load_a, LB&& load_b) {
+                                          int wave, int lane, int t, int b_row, int b_kq,
+                                          LA&& load_a, LB&& load_b) {
   using T = Tile<BM, BN>;
   using X = X3Tile<BN>;
   using G = ColGroups<T::TN>;
@@ -805,7 +806,9 @@ __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
   unsigned char* lds = reinterpret_cast<unsigned char*>(ldsf);
   const int li = lane & 15, fk = lane >> 4;
   const int row = t >> 2, kq = t & 3;
-  const bool b_on = t < BK * BN / 4;   // B rows 0..BN-1 (four staging threads each)
+  // the thread's B staging slot: column b_row of the tile, k chunk b_kq (dgrad: (t >> 2, t & 3)
+  // like A; forward: (t & 63, t >> 6), see the kernel's load_b)
+  const bool b_on = b_row < BN;
   // register sets: step k lives in set k % kX3Sets
   f32x4 a0[kX3Sets][AS], a1[kX3Sets][AS], b0[kX3Sets][T::BV], b1[kX3Sets][T::BV];
   auto gload = [&](int set) __attribute__((always_inline)) {
@@ -821,7 +824,7 @@ __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
     *reinterpret_cast<u32x4*>(pa + 2 * X::PA) = p2;
     if (b_on) {
       x3_split(b0[set][0], b1[set][0], p0, p1, p2);
-      unsigned char* pb = st + 3 * X::PA + row * X::ROWB + kq * 16;
+      unsigned char* pb = st + 3 * X::PA + b_row * X::ROWB + b_kq * 16;
       *reinterpret_cast<u32x4*>(pb) = p0;
       *reinterpret_cast<u32x4*>(pb + X::PB) = p1;
       *reinterpret_cast<u32x4*>(pb + 2 * X::PB) = p2;
@@ -936,7 +939,7 @@ template <int BM, int BN, bool BTRANS, int KS, int ABL = 0, int ROLE = 0, bool P
           bool PAIR = false, bool AFF = false, bool X3 = false>
 __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
-  static_assert(!X3 || (BTRANS && PIPE && !PAIR && !AFF && ABL == 0), "bf16x3 loop: dgrad only");
+  static_assert(!X3 || (PIPE && !PAIR && !AFF && ABL == 0 && BN <= 64), "bf16x3 loop: no loader fusion");
   constexpr int LDS_X3 = X3Tile<BN>::LDS_FLOATS > T::C_SZ + 512 ? X3Tile<BN>::LDS_FLOATS : T::C_SZ + 512;
   constexpr int LDS_TILES = X3 ? LDS_X3 : (PAIR ? T::LDSF2 : T::LDSF);
   __shared__ __attribute__((aligned(16))) float lds[LDS_TILES + (AFF ? 3 * kAffMaxC : 0)];
@@ -1137,8 +1140,23 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
         ra[AS + 3][0] = __builtin_bit_cast(float, okbits);
       }
     };
+    // bf16x3 forward: the stage needs, per column n, four CONSECUTIVE k of the [k][n] weights in one
+    // thread (they become one 16-byte bf16 chunk).  Thread (n = t & 63, chunk = wave) fetches them
+    // as four dword loads; across a wave each of them is one contiguous 256-byte row segment.
+    const int x3_col = n0 + (t & 63);
+    const bool x3_bok = (t & 63) < BN && x3_col < p.n_lim;
+    const int x3_boff = 4 * ((4 * (t >> 6)) * p.d_row + x3_col);
     auto load_b = [&](f32x4 (&rb)[T::BV]) __attribute__((always_inline)) {
       const bool kvalid = k_left > 0;
+      if constexpr (X3 && !BTRANS) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned off = (x3_bok && kvalid) ? (unsigned)(x3_boff + 4 * e * p.d_row + bbase) : kOOB;
+          v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dense, off, 0, 0));
+        }
+        rb[0] = v;
+      } else
 #pragma unroll
       for (int r = 0; r < T::BV; ++r) {
         const unsigned off = (bok[r] && kvalid) ? (unsigned)(boff[r] + bbase) : kOOB;
@@ -1195,7 +1213,8 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     };
     GS_STAMP(st_l0)
     if constexpr (X3)
-      x3_k_loop<BM, BN, AX>(nk, lds, acc, wave, lane, t, load_a, load_b);
+      x3_k_loop<BM, BN, AX>(nk, lds, acc, wave, lane, t, BTRANS ? (t >> 2) : (t & 63),
+                            BTRANS ? (t & 3) : (t >> 6), load_a, load_b);
     else if constexpr (PAIR)
       pipelined_k_loop_pairs<BM, BN, AX>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
     else
@@ -1841,6 +1860,16 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
     }
   }
   if constexpr (!BTRANS) {
+    // forward on the bf16x3 loop (no loader fusion, BN = 64), opt-in: the [k][n] weights have to be
+    // staged with eight dword loads per thread and step instead of two 16-byte ones, and over the
+    // forward shapes it is level with the fp32 loop (3x3 at stages 1 and 3 +5..10 %, the 1x1s
+    // -3..-5 %; profiles/r02_bf16x3_probe.md)
+    static const int x3_fwd = env_int("GS_X3_FWD", 0);
+    if (x3_fwd > 0 && !a.a_coeffs && pl.bm == 64 && pl.bn == 64 && pl.nk_per_split >= x3_fwd &&
+        (pl.splits == 1 || pl.nk_per_split >= 32)) {
+      hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, false, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
+      return;
+    }
     if (a.a_coeffs) {   // relu(bn(x)) evaluated in the loader: 64-row tiles (the planner's choice)
 #define GS_FAST_AFF(BN_)                                                                   \
   if (pl.bm == 64 && pl.bn == BN_) {                                                       \
