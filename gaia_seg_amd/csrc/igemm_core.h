@@ -1843,11 +1843,14 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
     // bf16x3 contraction (see x3_k_loop): stride-1 dgrad, 64-row tiles, BN 64 / 48.  r02 sweep over
     // the supernet's data-gradient shapes (profiles/r02_bf16x3_probe.md): +7.5 % in sum against the
     // fp32 loop, ahead everywhere except short split-K ranges (a split's 16 K steps are 8 bf16
-    // steps: the fill does not amortise), which keep the fp32 loop.  GS_X3=0 switches it off,
+    // steps: the fill does not amortise) and one-workgroup-per-CU launches, which keep the fp32 loop.  GS_X3=0 switches it off,
     // GS_X3=n (n > 1) raises the minimum K steps per workgroup.
     static const int x3_min = env_int("GS_X3", 1);
+    // (its single LDS stage wants co-resident workgroups to hide the two barriers per step: a
+    // launch of one workgroup per CU -- s3 1x1 256->1024, 30.5 vs 25.6 us -- keeps the fp32 loop)
     const bool x3_ok = x3_min > 0 && pl.bm == 64 && pl.nk_per_split >= x3_min &&
-                       (pl.splits == 1 || pl.nk_per_split >= 32);
+                       (pl.splits == 1 || pl.nk_per_split >= 48) &&
+                       (long)pl.tiles_m * pl.tiles_n * pl.splits >= 2L * kNumCU;
     if (x3_ok) {
       if (pl.bn == 64) {
         hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, true, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
@@ -1866,7 +1869,8 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
     // -3..-5 %; profiles/r02_bf16x3_probe.md)
     static const int x3_fwd = env_int("GS_X3_FWD", 0);
     if (x3_fwd > 0 && !a.a_coeffs && pl.bm == 64 && pl.bn == 64 && pl.nk_per_split >= x3_fwd &&
-        (pl.splits == 1 || pl.nk_per_split >= 32)) {
+        (pl.splits == 1 || pl.nk_per_split >= 48) &&
+        (long)pl.tiles_m * pl.tiles_n * pl.splits >= 2L * kNumCU) {
       hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, false, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
       return;
     }
