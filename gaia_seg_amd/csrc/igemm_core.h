@@ -1845,7 +1845,7 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
     // fp32 loop, ahead everywhere except short split-K ranges (a split's 16 K steps are 8 bf16
     // steps: the fill does not amortise) and one-workgroup-per-CU launches, which keep the fp32 loop.  GS_X3=0 switches it off,
     // GS_X3=n (n > 1) raises the minimum K steps per workgroup.
-    static const int x3_min = env_int("GS_X3", 1);
+    static const int x3_min = env_int("GS_X3", 4);   // (3 K steps = 2 bf16 steps, a quarter wasted: -10 %)
     // (its single LDS stage wants co-resident workgroups to hide the two barriers per step: a
     // launch of one workgroup per CU -- s3 1x1 256->1024, 30.5 vs 25.6 us -- keeps the fp32 loop)
     const bool x3_ok = x3_min > 0 && pl.bm == 64 && pl.nk_per_split >= x3_min &&
