@@ -1,7 +1,7 @@
 // Library identification and error text of the gaiaseg_hip C-ABI.
 #include "common.h"
 
-extern "C" int gs_abi_version(void) { return 5; }
+extern "C" int gs_abi_version(void) { return 6; }
 
 extern "C" const char* gs_target_arch(void) { return "gfx950"; }
 
@@ -27,6 +27,27 @@ extern "C" int gs_debug_force_plan(int bm, int bn, int splits) {
     if ((bm != 64 && bm != 128) || !bn_ok || splits < 1) return GS_E_BADARG;
   }
   gs::g_force_plan[0] = bm; gs::g_force_plan[1] = bn; gs::g_force_plan[2] = splits;
+  return GS_OK;
+}
+
+// Dispatch observability for the parity tests (see gs_debug_launch in the header).
+namespace gs {
+thread_local gs_debug_launch g_last_launch = {-1, 0, 0, 0, 0, 0, 0, 0};
+long long g_launch_counts[3][4][3] = {};
+}
+extern "C" int gs_debug_last_conv_launch(gs_debug_launch* out) {
+  if (!out) return GS_E_NULL;
+  if (gs::g_last_launch.op < 0) return GS_E_BADARG;
+  *out = gs::g_last_launch;
+  return GS_OK;
+}
+extern "C" int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset) {
+  for (int o = 0; o < 3; ++o)
+    for (int k = 0; k < 4; ++k)
+      for (int m = 0; m < 3; ++m) {
+        if (counts) counts[(o * 4 + k) * 3 + m] = __atomic_load_n(&gs::g_launch_counts[o][k][m], __ATOMIC_RELAXED);
+        if (reset) __atomic_store_n(&gs::g_launch_counts[o][k][m], 0LL, __ATOMIC_RELAXED);
+      }
   return GS_OK;
 }
 

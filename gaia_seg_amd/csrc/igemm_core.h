@@ -750,7 +750,7 @@ __device__ __forceinline__ void pipelined_k_loop_pairs(
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16x3 K loop (experimental, GS_X3=<min K steps>): the fp32 contraction as SIX bf16 MFMAs over an
+// bf16x3 K loop (stride-1 data gradient by default, GS_X3=<min K steps>, 0 = off): the fp32 contraction as SIX bf16 MFMAs over an
 // exact three-way bf16 split of both operands (x = x0 + x1 + x2 with 8 mantissa bits each; products
 // a_i * b_j for i + j <= 2, smallest first, fp32 accumulation in v_mfma_f32_16x16x32_bf16): as
 // accurate as the fp32 MFMA against fp64 (profiles/r02_bf16x3_probe.md) at 6 x 16 instead of
@@ -759,8 +759,13 @@ __device__ __forceinline__ void pipelined_k_loop_pairs(
 // chunk per piece; any k order works as long as both operands use it).  Operands are split ONCE,
 // at the stage store; LDS holds [piece][row][32 bf16 + 16 B pad] (80-byte rows: conflict-free
 // 16-byte fragment reads).  Both operands must be k-contiguous per row: dgrad (BTRANS) only.
-// Global loads run four steps ahead of the MFMAs (four register sets), the split + stage store
-// one step ahead (two LDS stages, one barrier per step).
+// Global loads run kX3Sets = 2 steps ahead of the MFMAs (two register sets); the split + stage store
+// of step i+1 follows the MFMAs of step i into the SAME single LDS stage (kX3Stages = 1: one barrier
+// before the store frees the stage, one after publishes it) -- 112 VGPRs and 31 KB of LDS, i.e. four
+// workgroups per CU, which is where the loop's speed comes from.
+// Non-finite operands: x3_split turns +-Inf into (Inf, NaN, NaN) pieces (Inf - Inf), so an output
+// that contracts an overflowed element becomes NaN where the fp32 MFMA loop would give +-Inf; NaN
+// stays NaN.  Finite inputs (the only case the parity bar covers) are split exactly.
 // ------------------------------------------------------------------------------------------
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -1687,6 +1692,17 @@ struct Plan {
 static const int kBN[6] = {128, 96, 80, 64, 48, 32};
 constexpr size_t kMaxSlabBytes = 96u << 20;
 
+// What the last implicit-GEMM launch of this thread was (gs_debug_last_conv_launch) and how many
+// launches each (op, K loop) pair has seen in this process (gs_debug_conv_launch_counts): lets the
+// parity tests assert WHICH K loop produced the numbers they compare (capi_misc.hip owns the storage).
+extern thread_local gs_debug_launch g_last_launch;
+extern long long g_launch_counts[3][4][3];
+static inline void note_launch(int op, int kloop, const Plan& pl, bool aff, int bw_mode) {
+  g_last_launch = gs_debug_launch{op, kloop, pl.bm, pl.bn, pl.splits, pl.nk_per_split, aff ? 1 : 0,
+                                  bw_mode};
+  __atomic_fetch_add(&g_launch_counts[op][kloop][bw_mode < 0 || bw_mode > 2 ? 0 : bw_mode], 1LL, __ATOMIC_RELAXED);
+}
+
 // Tuning knobs (read once): GS_WG_TARGET = workgroups a launch should reach before we stop
 // shrinking tiles / splitting K (default 2 per CU); GS_MIN_KSTEPS = K steps per split at least.
 static int env_int(const char* name, int dflt) {
@@ -1813,6 +1829,7 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
 template <bool BTRANS, bool DIVS, bool SCALAR, int KS>
 static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
   const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
+  note_launch(BTRANS ? GS_OP_DGRAD : GS_OP_FORWARD, GS_KLOOP_GENERIC, pl, false, 0);
 #define GS_ROWS(BM_, BN_)                                                                     \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                         \
     hipLaunchKernelGGL((igemm_rows_kernel<BM_, BN_, BTRANS, DIVS, SCALAR, KS>), grid, block, 0, st, a); \
@@ -1821,6 +1838,40 @@ static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
   GS_ROWS(128, 128) GS_ROWS(128, 96) GS_ROWS(128, 80) GS_ROWS(128, 64) GS_ROWS(128, 48) GS_ROWS(128, 32)
   GS_ROWS(64, 128) GS_ROWS(64, 96) GS_ROWS(64, 80) GS_ROWS(64, 64) GS_ROWS(64, 48) GS_ROWS(64, 32)
 #undef GS_ROWS
+}
+
+// K loop of a fast row launch (GS_KLOOP_*).  bf16x3 contraction (see x3_k_loop): stride-1 dgrad,
+// 64-row tiles, BN 64 / 48.  r02 sweep over the supernet's data-gradient shapes
+// (profiles/r02_bf16x3_probe.md): +7.5 % in sum against the fp32 loop, ahead everywhere except short
+// split-K ranges (a split's 16 K steps are 8 bf16 steps: the fill does not amortise) and
+// one-workgroup-per-CU launches (its single LDS stage wants co-resident workgroups to hide the two
+// barriers per step: s3 1x1 256->1024, 30.5 vs 25.6 us), which keep the fp32 loop.  GS_X3=0 switches
+// it off, GS_X3=n (n > 1) raises the minimum K steps per workgroup (3 K steps = 2 bf16 steps, a
+// quarter wasted: -10 %).  The forward runs on it only behind GS_X3_FWD=<min K steps> (the [k][n]
+// weights are staged with eight dword loads per thread and step: level with the fp32 loop).
+// Long K ranges otherwise run two K steps per barrier (pipelined_k_loop_pairs) when the launch has at
+// most three workgroups per CU anyway (its four LDS stages allow no more); big grids and short K
+// ranges keep the two-stage loop, whose smaller footprint lets five workgroups per CU overlap their
+// fill / drain (r01 A/B: s2..s4 3x3 and the head convs +3..7 %, s1 3x3 -3 % if paired).
+static inline bool pair_loop_ok(const Plan& pl) {
+  return pl.nk_per_split >= pair_min_ksteps() &&
+         (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
+}
+static inline bool x3_grid_ok(const Plan& pl, int min_ksteps_) {
+  return min_ksteps_ > 0 && pl.bm == 64 && pl.nk_per_split >= min_ksteps_ &&
+         (pl.splits == 1 || pl.nk_per_split >= 48) &&
+         (long)pl.tiles_m * pl.tiles_n * pl.splits >= 2L * kNumCU;
+}
+template <bool BTRANS>
+static inline int rows_fast_kloop(const Plan& pl, bool in_affine) {
+  if constexpr (BTRANS) {
+    static const int x3_min = env_int("GS_X3", 4);
+    if (x3_grid_ok(pl, x3_min) && (pl.bn == 64 || pl.bn == 48)) return GS_KLOOP_BF16X3;
+  } else {
+    static const int x3_fwd = env_int("GS_X3_FWD", 0);
+    if (!in_affine && x3_grid_ok(pl, x3_fwd) && pl.bn == 64) return GS_KLOOP_BF16X3;
+  }
+  return pair_loop_ok(pl) ? GS_KLOOP_FP32_PAIRS : GS_KLOOP_FP32;
 }
 
 template <bool BTRANS, int KS, int ROLE = 0>
@@ -1833,47 +1884,21 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
     a.tile_order = force >= 0 ? force : (b_bytes > a_bytes ? 1 : 0);
   }
   const dim3 grid(pl.tiles_m * pl.tiles_n * pl.splits), block(NT);
-  // long K ranges run two K steps per barrier (pipelined_k_loop_pairs) when the launch has at most
-  // three workgroups per CU anyway (its four LDS stages allow no more); big grids and short K
-  // ranges keep the two-stage loop, whose smaller footprint lets five workgroups per CU overlap
-  // their fill / drain (r01 A/B: s2..s4 3x3 and the head convs +3..7 %, s1 3x3 -3 % if paired)
-  const bool pair = pl.nk_per_split >= pair_min_ksteps() &&
-                    (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
-  if constexpr (BTRANS) {
-    // bf16x3 contraction (see x3_k_loop): stride-1 dgrad, 64-row tiles, BN 64 / 48.  r02 sweep over
-    // the supernet's data-gradient shapes (profiles/r02_bf16x3_probe.md): +7.5 % in sum against the
-    // fp32 loop, ahead everywhere except short split-K ranges (a split's 16 K steps are 8 bf16
-    // steps: the fill does not amortise) and one-workgroup-per-CU launches, which keep the fp32 loop.  GS_X3=0 switches it off,
-    // GS_X3=n (n > 1) raises the minimum K steps per workgroup.
-    static const int x3_min = env_int("GS_X3", 4);   // (3 K steps = 2 bf16 steps, a quarter wasted: -10 %)
-    // (its single LDS stage wants co-resident workgroups to hide the two barriers per step: a
-    // launch of one workgroup per CU -- s3 1x1 256->1024, 30.5 vs 25.6 us -- keeps the fp32 loop)
-    const bool x3_ok = x3_min > 0 && pl.bm == 64 && pl.nk_per_split >= x3_min &&
-                       (pl.splits == 1 || pl.nk_per_split >= 48) &&
-                       (long)pl.tiles_m * pl.tiles_n * pl.splits >= 2L * kNumCU;
-    if (x3_ok) {
-      if (pl.bn == 64) {
+  const int kloop = rows_fast_kloop<BTRANS>(pl, a.a_coeffs != nullptr);
+  const bool pair = kloop == GS_KLOOP_FP32_PAIRS;
+  note_launch(BTRANS ? GS_OP_DGRAD : GS_OP_FORWARD, kloop, pl, a.a_coeffs != nullptr, a.bw_mode);
+  if (kloop == GS_KLOOP_BF16X3) {
+    if constexpr (BTRANS) {
+      if (pl.bn == 64)
         hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, true, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
-        return;
-      }
-      if (pl.bn == 48) {
+      else
         hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 48, true, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
-        return;
-      }
+    } else {
+      hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, false, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
     }
+    return;
   }
   if constexpr (!BTRANS) {
-    // forward on the bf16x3 loop (no loader fusion, BN = 64), opt-in: the [k][n] weights have to be
-    // staged with eight dword loads per thread and step instead of two 16-byte ones, and over the
-    // forward shapes it is level with the fp32 loop (3x3 at stages 1 and 3 +5..10 %, the 1x1s
-    // -3..-5 %; profiles/r02_bf16x3_probe.md)
-    static const int x3_fwd = env_int("GS_X3_FWD", 0);
-    if (x3_fwd > 0 && !a.a_coeffs && pl.bm == 64 && pl.bn == 64 && pl.nk_per_split >= x3_fwd &&
-        (pl.splits == 1 || pl.nk_per_split >= 48) &&
-        (long)pl.tiles_m * pl.tiles_n * pl.splits >= 2L * kNumCU) {
-      hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, false, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
-      return;
-    }
     if (a.a_coeffs) {   // relu(bn(x)) evaluated in the loader: 64-row tiles (the planner's choice)
 #define GS_FAST_AFF(BN_)                                                                   \
   if (pl.bm == 64 && pl.bn == BN_) {                                                       \
@@ -1912,8 +1937,8 @@ static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t
   IgemmArgs a = a_in;
   a.nsplits = pl.splits;
   const dim3 grid(pl.tiles_m * pl.tiles_n * pl.splits), block(NT);
-  const bool pair = pl.nk_per_split >= pair_min_ksteps() &&
-                    (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
+  const bool pair = pair_loop_ok(pl);
+  note_launch(GS_OP_WGRAD, pair ? GS_KLOOP_FP32_PAIRS : GS_KLOOP_FP32, pl, a.a_coeffs != nullptr, 0);
   static const int no_walign = env_int("GS_NO_WALIGN", 0);
   const bool walign = !no_walign && a.Wp % BK == 0;
   if (a.a_coeffs) {
@@ -1953,6 +1978,7 @@ static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t
 template <bool SCALAR, int KS>
 static void launch_wgrad(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
   const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
+  note_launch(GS_OP_WGRAD, GS_KLOOP_GENERIC, pl, false, 0);
 #define GS_WG(BM_, BN_)                                                                \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                  \
     hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, SCALAR, KS>), grid, block, 0, st, a); \

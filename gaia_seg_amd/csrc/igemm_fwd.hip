@@ -136,3 +136,46 @@ extern "C" int gs_debug_query_plan(int32_t M, int32_t N, int32_t K, int32_t max_
   *bm = pl.bm; *bn = pl.bn; *splits = pl.splits; *ksteps_per_split = pl.nk_per_split;
   return GS_OK;
 }
+
+// Test hook: what the three conv entry points would launch for this descriptor (mirrors their
+// dispatch; tests/test_hip_ops_gpu.py asserts it equals gs_debug_last_conv_launch after real calls).
+extern "C" int gs_debug_query_conv_launch(const gs_conv_desc* d, int32_t op, gs_debug_launch* out) {
+  if (!out) return GS_E_NULL;
+  int rc = check_desc(d);
+  if (rc != GS_OK) return rc;
+  if (op < GS_OP_FORWARD || op > GS_OP_WGRAD) return GS_E_BADARG;
+  const int ks = ksize_tag(d);
+  const bool vec = x_is_vector(d);
+  const bool no_fast = getenv("GS_NO_FAST") != nullptr;
+  const size_t w_bytes = (size_t)d->KH * d->KW * d->Ci_max * d->Co_ld * sizeof(float);
+  Plan pl{};
+  int kloop = GS_KLOOP_GENERIC;
+  const bool aff = d->in_affine != nullptr && op != GS_OP_DGRAD;
+  if (op == GS_OP_FORWARD) {
+    pl = plan_fwd(d);
+    const size_t src_b = (size_t)d->N * d->x_sn * sizeof(float);
+    if (vec && fast_rows_ok(d->Ci, ks, src_b, w_bytes) && !no_fast)
+      kloop = rows_fast_kloop<false>(pl, aff);
+  } else if (op == GS_OP_DGRAD) {
+    const size_t dy_b = (size_t)d->N * d->Ho * d->Wo * d->ldy * sizeof(float);
+    const bool fast = fast_rows_ok(d->Co, ks, dy_b, w_bytes) && !no_fast;
+    if (d->stride > 1 && fast && (long)d->N * d->H * d->W * d->x_sw < (1L << 31)) {
+      const int s = d->stride;
+      const TapAxis th = tap_axis(0, d->pad, d->dil, s, d->KH), tw = tap_axis(0, d->pad, d->dil, s, d->KW);
+      const long Mc = (long)d->N * class_len(d->H, s, 0) * class_len(d->W, s, 0);
+      pl = make_plan((int)Mc, d->Ci, std::max(1, th.n * tw.n) * d->Co, true);
+      kloop = rows_fast_kloop<true>(pl, false);
+    } else {
+      pl = plan_dgrad(d);
+      if (d->stride == 1 && fast) kloop = rows_fast_kloop<true>(pl, false);
+    }
+  } else {
+    pl = plan_wgrad(d);
+    const size_t src_b = (size_t)d->N * d->x_sn * sizeof(float);
+    const size_t dy_b = (size_t)d->N * d->Ho * d->Wo * d->ldy * sizeof(float);
+    if (vec && src_b < (1ull << 31) && dy_b < (1ull << 31) && !no_fast)
+      kloop = pair_loop_ok(pl) ? GS_KLOOP_FP32_PAIRS : GS_KLOOP_FP32;
+  }
+  *out = gs_debug_launch{op, kloop, pl.bm, pl.bn, pl.splits, pl.nk_per_split, aff ? 1 : 0, 0};
+  return GS_OK;
+}

@@ -16,7 +16,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgaiaseg_hip.so")
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HipLibraryError(RuntimeError):
@@ -46,6 +46,16 @@ class BnBwdFuse(Structure):
     _fields_ = [("y", c_void_p), ("act", c_void_p), ("coeffs", c_void_p), ("sums", c_void_p),
                 ("fused", POINTER(c_int32)), ("ldy", c_int32), ("ldact", c_int32), ("mode", c_int32),
                 ("reserved", c_int32)]
+
+
+class DebugLaunch(Structure):
+    """Mirror of ``gs_debug_launch``."""
+    _fields_ = [(k, c_int32) for k in ("op", "kloop", "bm", "bn", "splits", "ksteps_per_split",
+                                       "in_affine", "bn_bwd_mode")]
+
+
+OP_FORWARD, OP_DGRAD, OP_WGRAD = 0, 1, 2
+KLOOP_GENERIC, KLOOP_FP32, KLOOP_FP32_PAIRS, KLOOP_BF16X3 = 0, 1, 2, 3
 
 
 class CeDesc(Structure):
@@ -139,6 +149,9 @@ PROTOTYPES = {
     "gs_debug_force_plan": (_i32, [_i32, _i32, _i32]),
     "gs_debug_query_plan": (_i32, [_i32, _i32, _i32, _i32, POINTER(_i32), POINTER(_i32), POINTER(_i32),
                                    POINTER(_i32)]),
+    "gs_debug_last_conv_launch": (_i32, [POINTER(DebugLaunch)]),
+    "gs_debug_conv_launch_counts": (_i32, [POINTER(_i64), _i32]),
+    "gs_debug_query_conv_launch": (_i32, [_CD, _i32, POINTER(DebugLaunch)]),
     "gs_stream_fork": (_i32, [_P, _P]),
     "gs_conv_bn_workspace_bytes": (_sz, [_CD]),
     "gs_conv_bn_forward": (_i32, [_CD, _P, _P, _BN, _P, _i32, _P, _P, _P, _i32, _P, _sz, _P]),

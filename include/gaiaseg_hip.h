@@ -497,6 +497,35 @@ int gs_debug_force_plan(int32_t bm, int32_t bn, int32_t splits);
 int gs_debug_query_plan(int32_t M, int32_t N, int32_t K, int32_t max_splits, int32_t* bm,
                         int32_t* bn, int32_t* splits, int32_t* ksteps_per_split);
 
+/* Which kernel family and K loop an implicit-GEMM launch used.  The parity tests assert it, so that a
+ * comparison against F.conv2d is known to have exercised the loop it claims to (the stride-1 data
+ * gradient of every bottleneck conv, gaiaseg/models/utils/dynamic_res_layer.py:105-125, contracts on
+ * GS_KLOOP_BF16X3 when its grid is large enough and on the fp32 loops otherwise). */
+#define GS_OP_FORWARD 0
+#define GS_OP_DGRAD 1
+#define GS_OP_WGRAD 2
+#define GS_KLOOP_GENERIC 0      /* igemm_rows_kernel / igemm_wgrad_kernel: any shape, sectioned loop  */
+#define GS_KLOOP_FP32 1         /* fast kernels, v_mfma_f32_16x16x4_f32, one K step per barrier       */
+#define GS_KLOOP_FP32_PAIRS 2   /* the same, two K steps per barrier                                  */
+#define GS_KLOOP_BF16X3 3       /* six v_mfma_f32_16x16x32_bf16 over an exact 3-way bf16 split        */
+typedef struct gs_debug_launch {
+  int32_t op;                   /* GS_OP_*                                                            */
+  int32_t kloop;                /* GS_KLOOP_*                                                         */
+  int32_t bm, bn, splits, ksteps_per_split;
+  int32_t in_affine;            /* 1: relu(bn(x)) evaluated in the operand loader                     */
+  int32_t bn_bwd_mode;          /* dgrad: gs_bn_bwd_fuse mode folded into the tile epilogue (0 none)   */
+} gs_debug_launch;
+/* The most recent conv launch issued by the calling thread (a strided dgrad reports its last parity
+ * class).  GS_E_BADARG if the thread has not launched any. */
+int gs_debug_last_conv_launch(gs_debug_launch* out);
+/* counts[(op * 4 + kloop) * 3 + bn_bwd_mode] = launches since the last reset (process-wide, 36
+ * entries); reset != 0 clears after reading.  counts may be NULL (reset only). */
+int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset);
+/* What gs_conv2d_forward / _dgrad / _wgrad (op = GS_OP_*) WOULD launch for this descriptor: host
+ * arithmetic only, no GPU needed (honours gs_debug_force_plan and the GS_X3 switches).  For a strided
+ * dgrad it describes the parity class (0, 0). */
+int gs_debug_query_conv_launch(const gs_conv_desc* d, int32_t op, gs_debug_launch* out);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Stream fork / join: work enqueued on `to` after this call waits for everything enqueued on  */
 /* `from` before it (hipEventRecord + hipStreamWaitEvent on an internal event ring).  Used to   */

@@ -107,3 +107,41 @@ def test_conv_planner_invariants_need_no_gpu():
     assert sp > 1 and (tiles * sp) % 256 == 0
     # the least-padded width wins when the tile count is comparable
     assert _plan(L, 16384, 96, 864)[1] == 48
+
+
+def test_x3_dgrad_cases_pass_the_dispatch_gate_without_gpu():
+    """The operator cases of tests/test_dgrad_x3_gpu.py are sized to reach the bf16x3 data-gradient
+    loop.  gs_debug_query_conv_launch is host arithmetic, so the claim is checked here already (the
+    GPU test re-checks it against the launch that really happened)."""
+    if os.environ.get("GS_X3", "4") == "0":
+        pytest.skip("bf16x3 switched off")
+    from test_dgrad_x3_gpu import X3_CASES, _desc
+    L = lib.load()
+    seen_bn, seen_split, seen_odd = set(), False, False
+    for case in X3_CASES:
+        n, h, w, ci, co, k, dil, ci_max, co_ld, ldx, ldy, acc, force = case
+        d = _desc(lib, n, h, w, ci, co, k, dil, ci_max, co_ld, ldx, ldy)
+        if force:
+            assert L.gs_debug_force_plan(*force) == 0
+        q = lib.DebugLaunch()
+        try:
+            assert L.gs_debug_query_conv_launch(ctypes.byref(d), lib.OP_DGRAD, ctypes.byref(q)) == 0
+        finally:
+            L.gs_debug_force_plan(0, 0, 0)
+        if case is X3_CASES[-1]:
+            assert q.kloop != lib.KLOOP_BF16X3 and q.splits == 4 and q.ksteps_per_split < 48
+            continue
+        assert q.kloop == lib.KLOOP_BF16X3, case
+        tiles = -(-n * h * w // 64) * -(-ci // q.bn) * q.splits
+        assert q.bm == 64 and q.bn in (64, 48) and tiles >= 512 and q.ksteps_per_split >= 4
+        seen_bn.add(q.bn)
+        seen_split |= q.splits > 1 and q.ksteps_per_split >= 48
+        seen_odd |= q.splits == 1 and q.ksteps_per_split % 2 == 1
+    assert seen_bn == {64, 48} and seen_split and seen_odd
+    # forward and weight gradient of the same shape stay on the fp32 loops
+    d = _desc(lib, 2, 128, 136, 64, 256, 1, 1, 64, 256, 64, 256)
+    for op in (lib.OP_FORWARD, lib.OP_WGRAD):
+        assert L.gs_debug_query_conv_launch(ctypes.byref(d), op, ctypes.byref(q)) == 0
+        assert q.kloop in (lib.KLOOP_FP32, lib.KLOOP_FP32_PAIRS) and q.op == op
+    assert L.gs_debug_query_conv_launch(ctypes.byref(d), 7, ctypes.byref(q)) == -1
+    assert ctypes.sizeof(lib.DebugLaunch) == 8 * 4
