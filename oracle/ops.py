@@ -52,12 +52,21 @@ class ReluMasks:
     deep ReLU networks amplify rounding noise with depth (40+ residual blocks take 6e-8 to ~1e-3 of
     the activation RMS), so "within rounding of zero" is measured against what the reference's own
     fp32 arithmetic does at the same layer: witness_flips records the witness's disagreements with
-    this (fp64) side in the same units as flips."""
+    this (fp64) side in the same units as flips.  For small tensors (<= SMALL_PRE elements, e.g. the
+    PPM's pool-scale-1 branch: N x 512 x 1 x 1, BatchNorm over N values per channel) sign
+    disagreements are too few to be a statistic, so the witness also hands over its pre-activations
+    (`witness_pre`) and witness_noise[key] = max |x_fp32 - x_fp64| / rms is the fp32 arithmetic's own
+    error level at that layer."""
+    SMALL_PRE = 1 << 20
 
-    def __init__(self, masks=None, keep_own=False, pools=None, witness=None, keep_pre=False):
+    def __init__(self, masks=None, keep_own=False, pools=None, witness=None, keep_pre=False,
+                 witness_pre=None):
         self.masks = masks
         self.witness = witness     # key -> bool mask of ANOTHER fp32 implementation (the fp32 oracle):
         self.witness_flips = {}    #   its disagreements with this side's signs, recorded like flips
+        self.witness_pre = witness_pre or {}   # key -> the witness's pre-activation (small tensors)
+        self.witness_noise = {}    # key -> max |x_witness - x| / rms(x)
+        self.small_pre = {}        # keep_own: pre-activations of the small tensors
         self.keep_pre = keep_pre
         self.pools = pools         # key -> uint8 [N, C, Ho, Wo] tap index (kh * k + kw) of the maximum
         self.pool_flips = {}       # key -> (count, max (own max - chosen value) / rms(x))
@@ -71,6 +80,12 @@ class ReluMasks:
         own = x.detach() > 0
         if self.keep_own:
             self.own[key] = own
+            if x.numel() <= self.SMALL_PRE:
+                self.small_pre[key] = x.detach().clone()
+        if key in self.witness_pre:
+            xd = x.detach().double()
+            rms = float(xd.pow(2).mean().sqrt().clamp_min(1e-30))
+            self.witness_noise[key] = float((self.witness_pre[key].double() - xd).abs().max()) / rms
         if self.keep_pre:
             self.pre[key] = x.detach()
         if self.witness is not None and key in self.witness:

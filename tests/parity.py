@@ -20,7 +20,11 @@ PPM branch with pool scale 1 normalises TWO values per channel (bs 2), whose dif
 their size for two noise images.  For a parameter whose HIP gradient is more than 1e-3 from the fp64
 oracle, the oracle is therefore also run in fp32 (PyTorch-CPU, the reference's arithmetic) on the
 same branch pattern, and the HIP error must not exceed 3x the fp32 oracle's own error against fp64
-("next" #2).  The fp32 pass only happens when needed.
+("next" #2).  The fp32 pass only happens when needed.  The escape is bounded per step:
+every conditioned parameter's ratio hip_err / fp32_err is recorded, the maximum must stay <= 3 and the
+MEDIAN <= 1.5 (a kernel uniformly 2.9x noisier than PyTorch-CPU fp32 would not pass); with
+GS_PARITY_MARGINS=<file> the counts and ratios of every compared step are appended there
+(profiles/r03_parity_margins.md is built from it).
 """
 import os
 
@@ -31,6 +35,10 @@ from conftest import rel_err
 TOL = 1e-3          # BASELINE.json: 1e-3 rel fp32, forward and gradients alike
 FLIP_TOL = 1e-3     # a branch disagreement is legitimate only within this * rms of a tie
 COND_FACTOR = 3.0   # ill-conditioned parameters: HIP error <= 3 x (fp32 oracle error), both vs fp64
+COND_MEDIAN = 1.5   # ... and over all parameters that needed the rule the MEDIAN ratio stays <= 1.5: the
+                    # rule excuses fp32 conditioning, not a kernel that is systematically noisier than
+                    # PyTorch-CPU fp32
+MARGINS_LOG = os.environ.get("GS_PARITY_MARGINS")   # path: one JSON line per compared step
 VERBOSE = bool(os.environ.get("GS_PARITY_VERBOSE"))
 
 
@@ -64,7 +72,7 @@ def hip_train_step(prod, img, gt, metas=None):
 
 def fp32_witness_masks(orc, img, gt):
     """ReLU masks of the oracle run natively in fp32 (PyTorch-CPU: the reference's arithmetic),
-    forward only; BN buffers are restored afterwards."""
+    forward only, plus its pre-activations where the tensor is small; BN buffers are restored."""
     from oracle import ops as O
     orc.float()
     bufs = {k: v.detach().clone() for k, v in orc.named_buffers()}
@@ -73,7 +81,7 @@ def fp32_witness_masks(orc, img, gt):
     with torch.no_grad():
         for k, b in orc.named_buffers():
             b.copy_(bufs[k])
-    return ctx.own
+    return ctx.own, ctx.small_pre
 
 
 def oracle_step(orc, img, gt, masks, pools, dtype=torch.float64, witness=None):
@@ -82,7 +90,8 @@ def oracle_step(orc, img, gt, masks, pools, dtype=torch.float64, witness=None):
     orc.to(dtype)
     for p in orc.parameters():
         p.grad = None
-    with O.ReluMasks(masks, pools=pools, witness=witness) as ctx:
+    witness, witness_pre = witness if isinstance(witness, tuple) else (witness, None)
+    with O.ReluMasks(masks, pools=pools, witness=witness, witness_pre=witness_pre) as ctx:
         losses = orc.forward_train(img.to(dtype), gt)
         loss, _ = orc.parse_losses(losses)
         loss.backward()
@@ -98,7 +107,10 @@ def check_flips(ctx, masks):
     total = 0
     worst = (0.0, None)
     for key, (n, rel) in ctx.flips.items():
-        wit = ctx.witness_flips.get(key, (0, 0.0))[1]
+        # the fp32 reference arithmetic's own level at this layer: its sign disagreements with fp64
+        # or, for small tensors where those are too few to be a statistic (PPM pool scale 1: BN over N
+        # values per channel), its largest pre-activation error
+        wit = max(ctx.witness_flips.get(key, (0, 0.0))[1], ctx.witness_noise.get(key, 0.0))
         assert rel <= max(FLIP_TOL, COND_FACTOR * wit), (
             "ReLU after %s: %d sign disagreement(s) at |x|/rms = %.2e (fp32 oracle: %.2e) — not a "
             "rounding-level flip" % (key, n, rel, wit))
@@ -174,6 +186,29 @@ def compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=True, check_b
         len(bad), [(k, "%.2e" % v) for k, v in bad[:12]],
         [(k, "hip %.2e vs fp32-oracle %.2e" % cond[k]) for k, _ in bad[:6] if k in cond])
     errs["_conditioned"] = len(cond)
+    ratios = sorted(h / max(e, 1e-300) for h, e in cond.values())
+    errs["_cond_ratio_median"] = ratios[len(ratios) // 2] if ratios else 0.0
+    errs["_cond_ratio_max"] = ratios[-1] if ratios else 0.0
+    n_grads = sum(1 for k in errs if k.startswith("grad:"))
+    if MARGINS_LOG:
+        import json
+        worst = max(cond.items(), key=lambda kv: kv[1][0] / max(kv[1][1], 1e-300)) if cond else None
+        rec = dict(test=os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], parameters=n_grads,
+                   conditioned=len(cond), ratio_median=errs["_cond_ratio_median"],
+                   ratio_p90=ratios[int(0.9 * (len(ratios) - 1))] if ratios else 0.0,
+                   ratio_max=errs["_cond_ratio_max"],
+                   worst=(worst[0], worst[1][0], worst[1][1]) if worst else None,
+                   hip_err_max_conditioned=max((h for h, _ in cond.values()), default=0.0),
+                   worst_unconditioned=max((v for k, v in errs.items() if k.startswith("grad:")),
+                                           default=0.0),
+                   loss_err=errs["loss"])
+        with open(MARGINS_LOG, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    # the escape is bounded: no parameter beyond COND_FACTOR (asserted above through `bad`), and the
+    # typical conditioned parameter is no noisier than the fp32 reference arithmetic itself
+    assert errs["_cond_ratio_median"] <= COND_MEDIAN, (
+        "%d conditioned parameters, median hip/fp32 error ratio %.2f > %.1f (max %.2f)"
+        % (len(cond), errs["_cond_ratio_median"], COND_MEDIAN, errs["_cond_ratio_max"]))
     return errs
 
 

@@ -4,12 +4,15 @@
             BasicBlock, dynamic_resnet.py:132-133), 512x512, bs 2, forward + backward
   config 2  FCN + R50..R101 supernet, 1024x512, bs 2: anchors MIN, R50, MAX and a seeded random draw
   config 3  PSP + aux FCN (the reference's pspnet_ar50to101v2_gsync model), 1024x512, bs 2, one rank
-  config 4  UPer + R101 anchor, 769x769 (bs 2 of the 4: every tile edge is ragged at 193/97/49/25)
+  config 4  UPer + R101 anchor, 769x769, bs 4 (every tile edge is ragged at 193/97/49/25)
+  OS8       the reference's v1c supernet (deep stem, dilations (1,1,2,4)) + PSP + aux, R50 anchor,
+            1024x512, bs 2
   config 5  OHEM(0.7, 100000) + aux train loss at 2048x1024 and whole / slide inference
             (crop 512x1024, stride 341x683)
 
 Protocol: tests/parity.py — one HIP step vs one fp64 oracle pass on the HIP path's ReLU branch
-pattern; losses, accuracy, BN running statistics and all parameter gradients at 1e-3 max norm.
+pattern; losses, accuracy, BN running statistics and all parameter gradients at 1e-3 max norm, with
+the bounded conditioning rule of tests/parity.py for parameters where fp32 itself cannot hold 1e-3.
 Weights: the real supernet at its real (max) sizes, random conv weights with He scale, BN gamma in
 U(0.5, 1.5), beta N(0, 0.1), norm3 not zeroed, dropout 0."""
 import os
@@ -152,9 +155,19 @@ def test_config3_psp_supernet_1024x512_bs2_single_rank(hip_lib):
 
 
 # ---- config 4 -------------------------------------------------------------------------------
-def test_config4_uper_r101_769x769(hip_lib):
-    # bs 2 of the config's 4: training-mode BN of the PPM's 1x1 pool needs more than one image
-    _train_case("upernet_ar50to101v2.py", ANCHORS["R101"], 2, 769, 769)
+def test_config4_uper_r101_769x769_bs4(hip_lib):
+    # the config's stated batch: 4 x 769 x 769 -> 148 996 rows at level 0 (ragged 193 / 97 / 49 / 25)
+    _train_case("upernet_ar50to101v2.py", ANCHORS["R101"], 4, 769, 769)
+
+
+# ---- OS8 / v1c ------------------------------------------------------------------------------
+def test_os8_v1c_psp_r50_1024x512_bs2(hip_lib):
+    """SURVEY.md 8d "report both OS32 and OS8": the reference's v1c supernet
+    (configs/local_examples/extract_subnet/psp_ar50to101_v1c_extract.py:6-14 -- deep stem, strides
+    (1,2,1,1), dilations (1,1,2,4), contract_dilation) with the PSP + aux heads at full size: dilated
+    bottleneck 3x3s at M = 16384 and the 2560+2048 -> 512 PSP bottleneck at 64 x 128."""
+    a = dict(ANCHORS["R50"], stem=[32, 32, 64])
+    _train_case("pspnet_ar50to101_v1c_os8.py", a, 2, 512, 1024)
 
 
 # ---- config 5 -------------------------------------------------------------------------------
