@@ -1,0 +1,180 @@
+"""The reference's own forward WIRING, pinned (CPU): tests/golden/ref_wiring.{npz,json} hold outputs and
+call traces of the reference's forward methods -- cut out of /root/reference by AST and run on
+plain-torch stand-in children by tests/golden/make_ref_wiring_fixtures.py (the reference is absent at
+test time).  oracle/model.py, given the same weights and inputs, must reproduce
+
+  * every output tensor (the stand-ins and the oracle's bricks are the same torch ops, so equality is
+    to rounding: a different loop bound, concat order or resize argument shows as an O(1) error), and
+  * the call trace: which child runs in which order on which shape, every resize's
+    (size, mode, align_corners).
+
+  DynamicResLayer.forward             gaiaseg/models/utils/dynamic_res_layer.py:166-172
+  DynamicResNet.forward               gaiaseg/models/backbones/dynamic_resnet.py:405-421
+  DynamicPPM.forward / PSPHead.forward  dynamic_psp_head.py:62-73, psp_head.py:228-241
+  DynamicUPerHead.forward             dynamic_uper_head.py:81-131
+  DynamicFCNHead.forward              dynamic_fcn_head.py:128-135 (+ fcn_head.py:179-202, 248-253)
+
+The product modules replay the same fixtures on the MI355X in tests/test_ref_wiring_gpu.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def wiring():
+    with open(os.path.join(GOLD, "ref_wiring.json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(GOLD, "ref_wiring.npz"))
+
+
+def state_dict_of(npz, prefix):
+    return {k[len(prefix):]: torch.from_numpy(npz[k]) for k in npz.files if k.startswith(prefix)}
+
+
+def close(a, b, tol=TOL):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < tol
+
+
+class OracleTrace:
+    """forward pre-hooks on the oracle's bricks + a recording oracle.ops.resize: the same
+    [(name, input shape, ...)] records as the generator's stand-ins write."""
+
+    def __init__(self, root, kinds, rename=lambda n: n):
+        from oracle import ops as O
+        self.records, self.handles, self.O = [], [], O
+        for name, m in root.named_modules():
+            if isinstance(m, kinds):
+                self.handles.append(m.register_forward_pre_hook(
+                    lambda mod, args, _n=rename(name): self.records.append([_n, list(args[0].shape)])))
+
+    def __enter__(self):
+        self._resize = self.O.resize
+
+        def resize(input, size=None, scale_factor=None, mode="nearest", align_corners=None):
+            self.records.append(["resize", list(input.shape),
+                                 [[int(s) for s in size], mode, bool(align_corners)]])
+            return self._resize(input, size, scale_factor, mode, align_corners)
+        self.O.resize = resize
+        return self
+
+    def __exit__(self, *exc):
+        self.O.resize = self._resize
+        for h in self.handles:
+            h.remove()
+        return False
+
+
+def ref_trace(trace, drop=("dropout",)):
+    """the reference trace in the oracle's vocabulary: (name, shape) for children, (+ args) for
+    resize; the p = 0 dropout call of the reference has no counterpart module in the oracle."""
+    out = []
+    for name, shape, extra in trace:
+        if name in drop:
+            continue
+        out.append([name, shape, extra] if name == "resize" else [name, shape])
+    return out
+
+
+def test_res_layer_runs_the_first_depth_state_blocks(wiring):
+    from oracle.model import OBottleneck, OResLayer
+    meta, npz = wiring
+    m = meta["res_layer"]
+    layer = OResLayer(m["inplanes"], m["planes"], m["depth_max"], stride=m["stride"])
+    layer.load_state_dict(state_dict_of(npz, "reslayer_sd/"), strict=False)
+    layer.train()
+    x = torch.from_numpy(npz["reslayer_x"])
+    for run in m["runs"]:
+        layer.depth_state = run["depth_state"]
+        with OracleTrace(layer, OBottleneck) as tr:
+            y = layer(x)
+        key = "reslayer_d%d%s_y" % (run["depth_state"], "_deploy" if run["deploying"] else "")
+        assert close(y, npz[key]), key
+        assert tr.records == ref_trace(run["trace"])
+        assert len(run["trace"]) == run["depth_state"]
+        if run["deploying"]:   # deploy_forward deletes the unused blocks, then runs the same loop
+            assert run["blocks_left"] == run["depth_state"]
+
+
+def test_backbone_forward_stem_stages_and_out_indices(wiring):
+    from oracle.model import OBottleneck, ODynamicResNet
+    meta, npz = wiring
+    for c in meta["resnet"]:
+        net = ODynamicResNet(3, c["stem_width"], c["width"], c["depth_max"], strides=tuple(c["strides"]),
+                             out_indices=tuple(c["out_indices"]), deep_stem=c["deep_stem"])
+        missing = net.load_state_dict(state_dict_of(npz, "resnet_%s_sd/" % c["tag"]), strict=False)
+        assert not [k for k in missing.missing_keys if "num_batches_tracked" not in k]
+        assert not missing.unexpected_keys
+        net.manipulate_arch({"body": {"depth": c["depth"]}})
+        net.train()
+        with OracleTrace(net, OBottleneck) as tr:
+            outs = net(torch.from_numpy(npz["resnet_%s_x" % c["tag"]]))
+        assert isinstance(outs, tuple) and len(outs) == c["n_outs"] == len(c["out_indices"])
+        for i, o in enumerate(outs):
+            assert close(o, npz["resnet_%s_out%d" % (c["tag"], i)], 1e-5), (c["tag"], i)
+        assert tr.records == ref_trace(c["trace"])
+        assert len(c["trace"]) == sum(c["depth"])
+
+
+def _head_inputs(npz, kind, tag):
+    feats, i = [], 0
+    while "%s_%s_in%d" % (kind, tag, i) in npz.files:
+        feats.append(torch.from_numpy(npz["%s_%s_in%d" % (kind, tag, i)]))
+        i += 1
+    return feats
+
+
+def _run_head(head, npz, kind, c):
+    from oracle.model import OConv, OConvModule
+    sd = state_dict_of(npz, "%s_%s_sd/" % (kind, c["tag"]))
+    res = head.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and not [k for k in res.missing_keys if "num_batches" not in k]
+    head.train()
+    with OracleTrace(head, (OConvModule,), ) as tr:
+        h = head.conv_seg.register_forward_pre_hook(
+            lambda mod, args: tr.records.append(["conv_seg", list(args[0].shape)]))
+        y = head(_head_inputs(npz, kind, c["tag"]))
+        h.remove()
+    assert close(y, npz["%s_%s_logits" % (kind, c["tag"])], 1e-5), (kind, c["tag"])
+    assert tr.records == ref_trace(c["trace"]), (kind, c["tag"])
+
+
+def test_psp_head_wiring(wiring):
+    from oracle.model import OPSPHead
+    meta, npz = wiring
+    for c in meta["psp"]:
+        head = OPSPHead(c["in_channels"], c["channels"], c["num_classes"], tuple(c["pool_scales"]),
+                        dropout_ratio=0.0, in_index=c["in_index"], align_corners=c["align_corners"])
+        _run_head(head, npz, "psp", c)
+        # psp_head.py:239 hands the channel record of the concat to the bottleneck as 2nd positional
+        # argument: [C4, 512 x len(pool_scales)] -- x first, then the pyramid levels in scale order
+        bott = [t for t in c["trace"] if t[0] == "bottleneck"][0]
+        assert bott[2] == [[c["in_channels"]] + [c["channels"]] * len(c["pool_scales"])]
+        assert bott[1][1] == c["in_channels"] + c["channels"] * len(c["pool_scales"])
+
+
+def test_uper_head_wiring(wiring):
+    from oracle.model import OUPerHead
+    meta, npz = wiring
+    for c in meta["uper"]:
+        head = OUPerHead(c["in_channels"], c["channels"], c["num_classes"],
+                         list(range(len(c["in_channels"]))), tuple(c["pool_scales"]),
+                         dropout_ratio=0.0, align_corners=c["align_corners"])
+        _run_head(head, npz, "uper", c)
+
+
+def test_fcn_head_wiring(wiring):
+    from oracle.model import OFCNHead
+    meta, npz = wiring
+    for c in meta["fcn"]:
+        head = OFCNHead(c["in_channels"], c["channels"], c["num_classes"], num_convs=c["num_convs"],
+                        kernel_size=c["kernel_size"], concat_input=c["concat_input"],
+                        dropout_ratio=0.0, in_index=c["in_index"])
+        _run_head(head, npz, "fcn", c)

@@ -1,0 +1,114 @@
+"""The product modules (HIP kernels) replay the reference-wiring fixtures of
+tests/golden/make_ref_wiring_fixtures.py on the MI355X: given the fixture's weights and inputs,
+DynamicResLayer / DynamicResNet / DynamicPSPHead / DynamicUPerHead / DynamicFCNHead of this package must
+produce the outputs the REFERENCE's own forward methods produced on plain-torch children
+(gaiaseg/models/utils/dynamic_res_layer.py:159-172, backbones/dynamic_resnet.py:405-421,
+decode_heads/dynamic_psp_head.py:62-73, psp_head.py:228-241, dynamic_uper_head.py:81-131,
+dynamic_fcn_head.py:128-135).  All convolution / BatchNorm weights are distinct random tensors, so a
+wrong concat-slice offset, block order, resize argument or top-down add order changes the logits by
+O(1); the tolerance only covers fp32 summation order."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_ref_wiring import GOLD, _head_inputs, close, state_dict_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 2e-4
+CONV, DBN, SBN = dict(type="DynConv2d"), dict(type="DynBN", requires_grad=True), dict(type="SyncBN", requires_grad=True)
+
+
+@pytest.fixture(scope="module")
+def wiring():
+    with open(os.path.join(GOLD, "ref_wiring.json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(GOLD, "ref_wiring.npz"))
+
+
+def _load(mod, sd):
+    res = mod.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert not [k for k in res.missing_keys if "num_batches_tracked" not in k], res.missing_keys
+    return mod.to(DEV).train()
+
+
+def _cl(x):
+    return torch.as_tensor(x).to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def test_res_layer_forward_and_deploy(hip_lib, wiring):
+    from gaia_seg_amd.core.bricks import DynamicBottleneck
+    from gaia_seg_amd.models.utils import DynamicResLayer
+    meta, npz = wiring
+    m = meta["res_layer"]
+    x = _cl(npz["reslayer_x"])
+    for run in m["runs"]:
+        layer = DynamicResLayer(DynamicBottleneck, m["inplanes"], m["planes"], depth=m["depth_max"],
+                                stride=m["stride"], conv_cfg=CONV, norm_cfg=DBN)
+        layer = _load(layer, state_dict_of(npz, "reslayer_sd/"))
+        layer.manipulate_depth(run["depth_state"])
+        if run["deploying"]:
+            layer._deploying = True
+        with torch.no_grad():
+            y = layer(x)
+        key = "reslayer_d%d%s_y" % (run["depth_state"], "_deploy" if run["deploying"] else "")
+        assert close(y.cpu(), npz[key], TOL), key
+        assert len(layer) == run["blocks_left"]     # deploy_forward drops the unused blocks
+
+
+def test_backbone_forward(hip_lib, wiring):
+    from gaia_seg_amd.models import build_backbone
+    meta, npz = wiring
+    for c in meta["resnet"]:
+        net = build_backbone(dict(type="DynamicResNet", in_channels=3, stem_width=c["stem_width"],
+                                  body_width=c["width"], body_depth=c["depth_max"], num_stages=4,
+                                  strides=tuple(c["strides"]), out_indices=tuple(c["out_indices"]),
+                                  deep_stem=c["deep_stem"], conv_cfg=CONV, norm_cfg=DBN, style="pytorch"))
+        net = _load(net, state_dict_of(npz, "resnet_%s_sd/" % c["tag"]))
+        net.manipulate_arch({"body": {"depth": c["depth"], "width": c["width"]}})
+        with torch.no_grad():
+            outs = net(torch.as_tensor(npz["resnet_%s_x" % c["tag"]]).to(DEV))
+        assert isinstance(outs, tuple) and len(outs) == c["n_outs"]
+        for i, o in enumerate(outs):
+            assert close(o.cpu(), npz["resnet_%s_out%d" % (c["tag"], i)], TOL), (c["tag"], i)
+
+
+def _head_case(kind, c, npz, cfg):
+    from gaia_seg_amd.models import build_head
+    cfg = dict(cfg, conv_cfg=CONV, norm_cfg=SBN, dropout_ratio=0.0, num_classes=c["num_classes"],
+               channels=c["channels"], align_corners=c.get("align_corners", False),
+               loss_decode=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=1.0))
+    head = _load(build_head(cfg), state_dict_of(npz, "%s_%s_sd/" % (kind, c["tag"])))
+    feats = [_cl(f) for f in _head_inputs(npz, kind, c["tag"])]
+    with torch.no_grad():
+        y = head(feats)
+    want = npz["%s_%s_logits" % (kind, c["tag"])]
+    assert tuple(y.shape) == want.shape
+    assert close(y.cpu(), want, TOL), (kind, c["tag"])
+
+
+def test_psp_head(hip_lib, wiring):
+    meta, npz = wiring
+    for c in meta["psp"]:
+        _head_case("psp", c, npz, dict(type="DynamicPSPHead", in_channels=c["in_channels"],
+                                       in_index=c["in_index"], pool_scales=tuple(c["pool_scales"])))
+
+
+def test_uper_head(hip_lib, wiring):
+    meta, npz = wiring
+    for c in meta["uper"]:
+        _head_case("uper", c, npz, dict(type="DynamicUPerHead", in_channels=c["in_channels"],
+                                        in_index=list(range(len(c["in_channels"]))),
+                                        pool_scales=tuple(c["pool_scales"])))
+
+
+def test_fcn_head(hip_lib, wiring):
+    meta, npz = wiring
+    for c in meta["fcn"]:
+        _head_case("fcn", c, npz, dict(type="DynamicFCNHead", in_channels=c["in_channels"],
+                                       in_index=c["in_index"], num_convs=c["num_convs"],
+                                       kernel_size=c["kernel_size"], concat_input=c["concat_input"]))
