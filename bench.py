@@ -39,6 +39,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# The bf16x3 K loop (six bf16 MFMAs per fp32 product, csrc/igemm_core.h x3_k_loop) is bounded by LDS
+# bandwidth, not by the MFMA pipe: 6 B per operand element -> 213 fp32-equivalent TFLOP/s at 100 % of the
+# LDS read rate (profiles/r02_bf16x3_probe.md).  A launch on that loop is priced against this figure.
+X3_LDS_BOUND_TFLOPS = 213.0
 
 
 def parse_args():
@@ -51,6 +55,13 @@ def parse_args():
                     help="'sample' = one subnet per step from the train sampler (config of record); "
                          "or an anchor name: MAX MIN R50 R77 R101")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the un-instrumented K-step pass is repeated this many times over the SAME K "
+                         "draws; `value` / `ms_per_step` are the MEDIAN pass, min / max go to `config`")
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "pipeline"],
+                    help="'pipeline' (diagnostics): every timed step's batch is produced by the GPU input "
+                         "pipeline (gs_seg_augment, datasets/gpu_pipeline.py) from resident uint8 "
+                         "2048x1024 images, so the input stage's cost per step is on record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", default="512x1024",
                     help="HxW of the bounded CPU sample (config batch size, R50 anchor)")
@@ -146,6 +157,34 @@ def cpu_baseline(cfg, size, seed, bs):
                        % (bs, h, w, dt, len(times)))
 
 
+class PipelineLoader:
+    """--data pipeline: every batch comes out of the GPU input pipeline (Resize(ratio 0.5-2) ->
+    RandomCrop -> RandomFlip -> PhotoMetricDistortion -> Normalize -> Pad, one gs_seg_augment launch
+    per sample) from a pool of resident uint8 2048x1024 "decoded" images (Cityscapes' size), on the
+    training stream, inside the timed step."""
+
+    def __init__(self, bs, size, seed, rank, dev, pool=6):
+        import torch
+        from gaia_seg_amd.datasets.gpu_pipeline import GpuTrainPipeline
+        g = torch.Generator().manual_seed(seed * 7919 + rank)
+        self.samples = []
+        for _ in range(pool):
+            img = torch.randint(0, 256, (1024, 2048, 3), generator=g, dtype=torch.uint8).to(dev)
+            lab = torch.randint(0, 19, (1024, 2048), generator=g, dtype=torch.uint8).to(dev)
+            self.samples.append((img, lab))
+        self.pipe = GpuTrainPipeline(crop_size=size, seed=seed + rank, device=dev, cat_max_ratio=1.0)
+        self.bs, self.i = bs, 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        n = len(self.samples)
+        batch = self.pipe.batch([self.samples[(self.i + j) % n] for j in range(self.bs)])
+        self.i += self.bs
+        return batch
+
+
 def launch_ranks(n):
     """--gpus N without a launcher: start N ranks as child processes (one per GPU, RCCL) and exit
     with their code.  Nothing in this parent touches the GPU (a process that has initialised HIP
@@ -165,10 +204,11 @@ def launch_ranks(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def first_step_check(model, cfg_path, seed, size, bs, arch_meta, batch, dev):
+def first_step_check(model, cfg_path, seed, size, bs, arch_meta, batch, dev, strict=False):
     """Run the first timed step's subnet and batch once from the initial weights with dropout off and
     compare the losses with the committed oracle values.  Returns the `check` entry; raises on a
-    mismatch.  (The BN running statistics it moves and the gradients it leaves are part of the
+    mismatch.  strict (the default configuration, seed and crop): a missing or stale fixture is an
+    error too, so the gate cannot disappear silently; diagnostic overrides report "skipped".  (The BN running statistics it moves and the gradients it leaves are part of the
     warm-up state; nothing of it is timed.)"""
     import torch
     from gaia_seg_amd.core.dynamic import fold_dict
@@ -181,11 +221,18 @@ def first_step_check(model, cfg_path, seed, size, bs, arch_meta, batch, dev):
     except (OSError, ValueError):
         gold = None
     if gold is None:
+        if strict:
+            raise SystemExit("bench.py: no committed oracle value for the default configuration (%s); "
+                             "regenerate tests/golden/bench_check.json or pass --no-check" % key)
         return dict(status="skipped", reason="no committed oracle value for %s" % key)
     csum = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
     if abs(csum - gold["param_abs_sum"]) > 1e-9 * gold["param_abs_sum"]:
-        return dict(status="skipped", reason="initial weights differ from the fixture's (RNG stream): "
-                    "abs-sum %.9g vs %.9g" % (csum, gold["param_abs_sum"]))
+        msg = ("initial weights differ from the fixture's (init order / RNG stream / layout changed): "
+               "abs-sum %.9g vs %.9g" % (csum, gold["param_abs_sum"]))
+        if strict:
+            raise SystemExit("bench.py: %s; regenerate tests/golden/bench_check.json (tests/golden/"
+                             "make_bench_check.py) or pass --no-check" % msg)
+        return dict(status="skipped", reason=msg)
     heads = [h for h in (model.decode_head, getattr(model, "auxiliary_head", None)) if h is not None]
     saved_h = [h.dropout for h in heads]
     for h in heads:
@@ -217,10 +264,12 @@ def first_step_check(model, cfg_path, seed, size, bs, arch_meta, batch, dev):
 
 def step_flops(model, sampler, seed, steps, size, bs, fixed_meta):
     """Algorithmic conv FLOPs of the timed steps (forward + dgrad + wgrad = 3x forward, the stem
-    conv has no dgrad): replays the seeded draws on the host after the timing."""
+    conv has no dgrad) and the K3 launches' algorithmic FLOPs / bytes: replays the seeded draws on the
+    host after the timing."""
     from gaia_seg_amd.core.dynamic import fold_dict
     from gaia_seg_amd.core.flops import _conv, model_flops
     total = 0.0
+    k3 = dict(launches=0, flops=0.0, bytes=0.0)
     if fixed_meta is None:
         sampler.seed(seed)
     for _ in range(steps):
@@ -228,9 +277,28 @@ def step_flops(model, sampler, seed, steps, size, bs, fixed_meta):
         model.manipulate_arch(fold_dict(meta)["arch"])
         f = model_flops(model, size[0], size[1])
         b = model.backbone
-        stem = 0.0 if b.deep_stem else _conv(b.conv1, 3, size[0], size[1])[0]
-        total += bs * (3.0 * f["total"] - stem)
-    return total
+        if b.deep_stem:
+            first = _conv(b.stem[0], 3, size[0], size[1])
+        else:
+            first = _conv(b.conv1, 3, size[0], size[1])
+        total += bs * (3.0 * f["total"] - first[0])   # the very first conv has no data gradient
+        # K3 = conv2 of every active bottleneck: algorithmic bytes x + W + y once
+        c, h, w = first[2], first[3], first[4]
+        if b.deep_stem:
+            for i in (3, 6):
+                _, _, c, h, w = _conv(b.stem[i], c, h, w)
+        mp = b.maxpool
+        h = (h + 2 * mp.padding - mp.kernel_size) // mp.stride + 1
+        w = (w + 2 * mp.padding - mp.kernel_size) // mp.stride + 1
+        for name in b.res_layers:
+            for blk in getattr(b, name).active_blocks():
+                _, _, c1, h1, w1 = _conv(blk.conv1, c, h, w)
+                f2, _, c2, h2, w2 = _conv(blk.conv2, c1, h1, w1)
+                _, _, c, h, w = _conv(blk.conv3, c2, h2, w2)
+                k3["launches"] += 1
+                k3["flops"] += bs * f2
+                k3["bytes"] += 4.0 * (bs * h1 * w1 * c1 + 9 * c1 * c2 + bs * h2 * w2 * c2)
+    return total, k3
 
 
 def main():
@@ -291,10 +359,16 @@ def main():
     fixed_meta = None
     if args.arch != "sample":
         anchors = {a["name"]: a for a in sampler.model_samplers[0].anchors}
-        fixed_meta = anchors[args.arch]
+        fixed_meta = dict(anchors[args.arch])
+        if cfg.get("stem_anchors"):   # deep-stem (v1c / OS8) supernet: a width per stem conv
+            fixed_meta["arch.backbone.stem.width"] = list(cfg["stem_anchors"][args.arch])
+    elif cfg.model["backbone"].get("deep_stem"):
+        raise SystemExit("bench.py: the deep-stem config needs --arch <anchor> (the in-tree train sampler "
+                         "draws one stem width, the deep stem takes three)")
 
-    bs = cfg.data["samples_per_gpu"]
-    size = tuple(cfg.crop_size)
+    data_cfg = cfg.get("data") or {}
+    bs = data_cfg.get("samples_per_gpu", 2)
+    size = tuple(cfg.get("crop_size") or (512, 1024))
     if args.crop:
         size = tuple(int(v) for v in args.crop.split("x"))
 
@@ -304,7 +378,10 @@ def main():
         first_meta = fixed_meta if fixed_meta is not None else sampler.sample()
         sampler.seed(args.seed)
         b0 = make_batch(bs, size[0], size[1], 19, args.seed * 1000003, dev)   # rank 0's first batch
-        check = first_step_check(model, args.config, args.seed, size, bs, first_meta, b0, dev)
+        default_cfg = os.path.join(ROOT, "configs/supernet/fcn_ar50to101v2.py")
+        strict = (os.path.abspath(args.config) == default_cfg and args.seed == 0 and not args.crop
+                  and args.arch in ("sample", "R50"))
+        check = first_step_check(model, args.config, args.seed, size, bs, first_meta, b0, dev, strict)
         arena.zero_grad()
         del b0
 
@@ -317,7 +394,10 @@ def main():
     runner.register_hook(PolyLrUpdaterHook(**lrc))
     runner.register_hook(ArenaOptimizerHook())
     runner.call_hook("before_run")
-    loader = SyntheticLoader(bs, size, num_classes=19, seed=args.seed, rank=rank, device=dev)
+    if args.data == "pipeline":
+        loader = PipelineLoader(bs, size, args.seed, rank, dev)
+    else:
+        loader = SyntheticLoader(bs, size, num_classes=19, seed=args.seed, rank=rank, device=dev)
     if args.step_graphs:
         runner.graphs_enabled = True
     # Start-up, untimed: capture the HIP graphs of the train sampler's named anchor subnets (they
@@ -372,8 +452,15 @@ def main():
         prof = cProfile.Profile()
         prof.enable()
     seg0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
-    elapsed = timed_pass(False)                      # <- `value`: nothing but the training steps
+    import ctypes
+    L.gs_debug_conv_launch_flops(None, 1)
+    passes = [timed_pass(False)]                     # <- `value`: nothing but the training steps
+    kl = (ctypes.c_double * 12)()
+    L.gs_debug_conv_launch_flops(kl, 1)              # which MFMA path carried the first pass's FLOPs
     seg_new = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0) - seg0
+    for _ in range(max(args.repeats, 1) - 1):        # same K draws again (the weights keep training)
+        passes.append(timed_pass(False))
+    elapsed = sorted(passes)[len(passes) // 2]       # the median pass: exactly K timed steps
     if prof is not None:
         prof.disable()
         import pstats
@@ -402,7 +489,6 @@ def main():
         # separate pass over the same draws with HIP events on the launch stream around every
         # bottleneck-conv2 forward (gs_k3_timer_*, include/gaiaseg_hip.h)
         elapsed_instr = timed_pass(True)
-        import ctypes
         c_n, c_ms, c_fl = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         lib.check(L.gs_k3_timer_read(ctypes.byref(c_n), ctypes.byref(c_ms), ctypes.byref(c_fl)),
                   "gs_k3_timer_read")
@@ -423,7 +509,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "fp32",
-            "data": "synthetic",
+            "data": "synthetic" if args.data == "synthetic" else "synthetic uint8 images through the GPU input pipeline",
             "config": {
                 "workload": "%s + aux FCN on the dynamic R50..R101 ResNet supernet (%s), %dx%d "
                             "crops, bs %d/GPU, arch=%s, fwd+bwd+SGD, random-init weights"
@@ -433,6 +519,13 @@ def main():
                 "parallelism": "dp%d" % world,
                 "allreduce_bytes_per_step_per_rank": int(bytes_per_step),
                 "last_loss": round(loss, 5),
+                "passes": {"repeats": len(passes), "value_is": "median pass",
+                           "images_per_sec_min": round(imgs / max(passes), 3),
+                           "images_per_sec_max": round(imgs / min(passes), 3),
+                           "ms_per_step_all": [round(1e3 * p / args.steps, 3) for p in passes]},
+                "input": ("GPU input pipeline (gs_seg_augment from resident uint8 2048x1024 images) "
+                          "inside every timed step" if args.data == "pipeline" else
+                          "resident synthetic fp32 batches"),
                 "device_mallocs_in_timed_steps": int(seg_new),
                 "contraction": "fp32 MFMA (forward, weight gradient); data gradient: six bf16 MFMAs "
                                "over an exact three-way bf16 split of both operands, fp32 "
@@ -447,14 +540,28 @@ def main():
         hooks = [h for h in runner.hooks if isinstance(h, ManipulateArchHook)]
         if hooks:
             out["config"]["archs"] = hooks[0].history[arch_log_start:arch_log_end]
-        fl = step_flops(model, sampler, args.seed, args.steps, size, bs, fixed_meta) * world
+        fl, k3_alg = step_flops(model, sampler, args.seed, args.steps, size, bs, fixed_meta)
+        fl *= world
+        # share of the launched contraction FLOPs per K loop (library counters over the first pass)
+        kl_tot = sum(kl) or 1.0
+        x3_share = sum(kl[o * 4 + 3] for o in range(3)) / kl_tot
+        fwd_tot = sum(kl[0:4]) or 1.0
+        blended = 1.0 / ((1.0 - x3_share) / FP32_MFMA_PEAK_TFLOPS + x3_share / X3_LDS_BOUND_TFLOPS)
+        ach_step = fl / elapsed / 1e12 / world
         out["roofline_step"] = {
             "what": "all convolutions of the %d timed steps, fwd + dgrad + wgrad (BN / pooling / loss "
                     "/ SGD carry no credited FLOPs)" % args.steps,
-            "bound": "mfma", "achieved": round(fl / elapsed / 1e12 / world, 2),
+            "bound": "mfma", "achieved": round(ach_step, 2),
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
-            "frac": round(fl / elapsed / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
-            "algorithmic_gflop_per_step_per_gpu": round(fl / args.steps / world / 1e9, 1)}
+            "frac": round(ach_step / FP32_MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_gflop_per_step_per_gpu": round(fl / args.steps / world / 1e9, 1),
+            "flop_share_by_k_loop": {"fp32_mfma": round(1.0 - x3_share, 4), "bf16x3": round(x3_share, 4)},
+            "blended_bound": round(blended, 1),
+            "frac_of_blended_bound": round(ach_step / blended, 4),
+            "bound_note": "`frac` divides fp32-equivalent FLOPs by the fp32 MFMA peak (157.3); the share "
+                          "of the FLOPs launched on the bf16x3 loop (stride-1 data gradients) is bounded "
+                          "by LDS bandwidth at %.0f fp32-equivalent TFLOP/s instead, so the step's "
+                          "bound is the harmonic blend above" % X3_LDS_BOUND_TFLOPS}
         if k3 is not None:
             launches, ms, flops, el_i = k3
             achieved = flops / (ms * 1e-3) / 1e12
@@ -469,6 +576,12 @@ def main():
                                                   "command)" % traffic_src,
                 "launches": launches, "avg_launch_us": round(1e3 * ms / launches, 2),
                 "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
+                "algorithmic_bytes_per_launch": int(k3_alg["bytes"] / max(k3_alg["launches"], 1)),
+                "algorithmic_check": "host replay of the %d draws: %d launches, %.3f GF per launch"
+                                     % (args.steps, k3_alg["launches"],
+                                        k3_alg["flops"] / max(k3_alg["launches"], 1) / 1e9),
+                "k_loop": "fp32 MFMA (v_mfma_f32_16x16x4_f32); forward FLOPs on the bf16x3 loop: %.1f %%"
+                          % (100.0 * kl[3] / fwd_tot),
                 "measured_in": "a separate instrumented pass over the same %d draws (%.3f ms/step; "
                                "`value` is from the un-instrumented pass)"
                                % (args.steps, 1e3 * el_i / args.steps),

@@ -3,7 +3,7 @@
 # strides (1, 2, 1, 1), dilations (1, 1, 2, 4), contract_dilation -- with the PSP decode head and the
 # aux FCN head of the in-tree training config.  Stages 3 and 4 run at 1/8 resolution (64 x 128 for a
 # 512 x 1024 crop): dilated 3x3 bottleneck convs at M = 16384 rows and a 348 GF/img PSP bottleneck.
-_base_ = ['../_dynamic_/model_samplers/ar50to101v2.py']
+_base_ = ['../_dynamic_/models/backbone_ar50to101v2.py', '../_dynamic_/model_samplers/ar50to101v2.py']
 model = dict(
     type='DynamicEncoderDecoder',
     backbone=dict(type='DynamicResNet', in_channels=3, stem_width=[32, 32, 64], deep_stem=True,

@@ -34,6 +34,7 @@ extern "C" int gs_debug_force_plan(int bm, int bn, int splits) {
 namespace gs {
 thread_local gs_debug_launch g_last_launch = {-1, 0, 0, 0, 0, 0, 0, 0};
 long long g_launch_counts[3][4][3] = {};
+double g_launch_flops[3][4] = {};
 }
 extern "C" int gs_debug_last_conv_launch(gs_debug_launch* out) {
   if (!out) return GS_E_NULL;
@@ -48,6 +49,15 @@ extern "C" int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset) {
         if (counts) counts[(o * 4 + k) * 3 + m] = __atomic_load_n(&gs::g_launch_counts[o][k][m], __ATOMIC_RELAXED);
         if (reset) __atomic_store_n(&gs::g_launch_counts[o][k][m], 0LL, __ATOMIC_RELAXED);
       }
+  return GS_OK;
+}
+
+extern "C" int gs_debug_conv_launch_flops(double* flops, int32_t reset) {
+  for (int o = 0; o < 3; ++o)
+    for (int k = 0; k < 4; ++k) {
+      if (flops) flops[o * 4 + k] = gs::g_launch_flops[o][k];
+      if (reset) gs::g_launch_flops[o][k] = 0.0;
+    }
   return GS_OK;
 }
 

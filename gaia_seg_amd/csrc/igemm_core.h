@@ -1697,7 +1697,10 @@ constexpr size_t kMaxSlabBytes = 96u << 20;
 // parity tests assert WHICH K loop produced the numbers they compare (capi_misc.hip owns the storage).
 extern thread_local gs_debug_launch g_last_launch;
 extern long long g_launch_counts[3][4][3];
-static inline void note_launch(int op, int kloop, const Plan& pl, bool aff, int bw_mode) {
+extern double g_launch_flops[3][4];   // algorithmic 2*M*N*K per (op, K loop); single-writer per stream thread
+static inline void note_launch(int op, int kloop, const Plan& pl, bool aff, int bw_mode,
+                               double flops = 0.0) {
+  g_launch_flops[op][kloop] += flops;
   g_last_launch = gs_debug_launch{op, kloop, pl.bm, pl.bn, pl.splits, pl.nk_per_split, aff ? 1 : 0,
                                   bw_mode};
   __atomic_fetch_add(&g_launch_counts[op][kloop][bw_mode < 0 || bw_mode > 2 ? 0 : bw_mode], 1LL, __ATOMIC_RELAXED);
@@ -1829,7 +1832,8 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
 template <bool BTRANS, bool DIVS, bool SCALAR, int KS>
 static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
   const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
-  note_launch(BTRANS ? GS_OP_DGRAD : GS_OP_FORWARD, GS_KLOOP_GENERIC, pl, false, 0);
+  note_launch(BTRANS ? GS_OP_DGRAD : GS_OP_FORWARD, GS_KLOOP_GENERIC, pl, false, 0,
+              2.0 * a.M * (double)a.Nn * a.Ktot);
 #define GS_ROWS(BM_, BN_)                                                                     \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                         \
     hipLaunchKernelGGL((igemm_rows_kernel<BM_, BN_, BTRANS, DIVS, SCALAR, KS>), grid, block, 0, st, a); \
@@ -1886,7 +1890,8 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
   const dim3 grid(pl.tiles_m * pl.tiles_n * pl.splits), block(NT);
   const int kloop = rows_fast_kloop<BTRANS>(pl, a.a_coeffs != nullptr);
   const bool pair = kloop == GS_KLOOP_FP32_PAIRS;
-  note_launch(BTRANS ? GS_OP_DGRAD : GS_OP_FORWARD, kloop, pl, a.a_coeffs != nullptr, a.bw_mode);
+  note_launch(BTRANS ? GS_OP_DGRAD : GS_OP_FORWARD, kloop, pl, a.a_coeffs != nullptr, a.bw_mode,
+              2.0 * a.M * (double)a.Nn * a.Ktot);
   if (kloop == GS_KLOOP_BF16X3) {
     if constexpr (BTRANS) {
       if (pl.bn == 64)
@@ -1938,7 +1943,8 @@ static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t
   a.nsplits = pl.splits;
   const dim3 grid(pl.tiles_m * pl.tiles_n * pl.splits), block(NT);
   const bool pair = pair_loop_ok(pl);
-  note_launch(GS_OP_WGRAD, pair ? GS_KLOOP_FP32_PAIRS : GS_KLOOP_FP32, pl, a.a_coeffs != nullptr, 0);
+  note_launch(GS_OP_WGRAD, pair ? GS_KLOOP_FP32_PAIRS : GS_KLOOP_FP32, pl, a.a_coeffs != nullptr, 0,
+              2.0 * a.M * (double)a.Nn * a.Ktot);
   static const int no_walign = env_int("GS_NO_WALIGN", 0);
   const bool walign = !no_walign && a.Wp % BK == 0;
   if (a.a_coeffs) {
@@ -1978,7 +1984,7 @@ static void launch_wgrad_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t
 template <bool SCALAR, int KS>
 static void launch_wgrad(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
   const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NT);
-  note_launch(GS_OP_WGRAD, GS_KLOOP_GENERIC, pl, false, 0);
+  note_launch(GS_OP_WGRAD, GS_KLOOP_GENERIC, pl, false, 0, 2.0 * a.M * (double)a.Nn * a.Ktot);
 #define GS_WG(BM_, BN_)                                                                \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                  \
     hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, SCALAR, KS>), grid, block, 0, st, a); \

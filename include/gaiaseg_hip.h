@@ -521,6 +521,11 @@ int gs_debug_last_conv_launch(gs_debug_launch* out);
 /* counts[(op * 4 + kloop) * 3 + bn_bwd_mode] = launches since the last reset (process-wide, 36
  * entries); reset != 0 clears after reading.  counts may be NULL (reset only). */
 int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset);
+/* flops[op * 4 + kloop] = algorithmic FLOPs (2 * M * N * K of the implicit GEMM, padding not counted)
+ * launched since the last reset: bench.py states which share of a step's contraction work ran on
+ * which MFMA path, so that its roofline fractions name the right bound.  Not thread-safe (one
+ * launching thread at a time, like the training step). */
+int gs_debug_conv_launch_flops(double* flops, int32_t reset);
 /* What gs_conv2d_forward / _dgrad / _wgrad (op = GS_OP_*) WOULD launch for this descriptor: host
  * arithmetic only, no GPU needed (honours gs_debug_force_plan and the GS_X3 switches).  For a strided
  * dgrad it describes the parity class (0, 0). */
