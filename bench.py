@@ -455,7 +455,7 @@ def main():
     import ctypes
     L.gs_debug_conv_launch_flops(None, 1)
     passes = [timed_pass(False)]                     # <- `value`: nothing but the training steps
-    kl = (ctypes.c_double * 12)()
+    kl = (ctypes.c_double * 15)()
     L.gs_debug_conv_launch_flops(kl, 1)              # which MFMA path carried the first pass's FLOPs
     seg_new = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0) - seg0
     for _ in range(max(args.repeats, 1) - 1):        # same K draws again (the weights keep training)
@@ -544,8 +544,8 @@ def main():
         fl *= world
         # share of the launched contraction FLOPs per K loop (library counters over the first pass)
         kl_tot = sum(kl) or 1.0
-        x3_share = sum(kl[o * 4 + 3] for o in range(3)) / kl_tot
-        fwd_tot = sum(kl[0:4]) or 1.0
+        x3_share = sum(kl[o * 5 + 3] for o in range(3)) / kl_tot
+        fwd_tot = sum(kl[0:5]) or 1.0
         blended = 1.0 / ((1.0 - x3_share) / FP32_MFMA_PEAK_TFLOPS + x3_share / X3_LDS_BOUND_TFLOPS)
         ach_step = fl / elapsed / 1e12 / world
         out["roofline_step"] = {

@@ -33,8 +33,9 @@ extern "C" int gs_debug_force_plan(int bm, int bn, int splits) {
 // Dispatch observability for the parity tests (see gs_debug_launch in the header).
 namespace gs {
 thread_local gs_debug_launch g_last_launch = {-1, 0, 0, 0, 0, 0, 0, 0};
-long long g_launch_counts[3][4][3] = {};
-double g_launch_flops[3][4] = {};
+long long g_launch_counts[3][GS_KLOOP_COUNT][3] = {};
+double g_launch_flops[3][GS_KLOOP_COUNT] = {};
+int g_stream_mode = -1;
 }
 extern "C" int gs_debug_last_conv_launch(gs_debug_launch* out) {
   if (!out) return GS_E_NULL;
@@ -44,18 +45,24 @@ extern "C" int gs_debug_last_conv_launch(gs_debug_launch* out) {
 }
 extern "C" int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset) {
   for (int o = 0; o < 3; ++o)
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < GS_KLOOP_COUNT; ++k)
       for (int m = 0; m < 3; ++m) {
-        if (counts) counts[(o * 4 + k) * 3 + m] = __atomic_load_n(&gs::g_launch_counts[o][k][m], __ATOMIC_RELAXED);
+        if (counts) counts[(o * GS_KLOOP_COUNT + k) * 3 + m] = __atomic_load_n(&gs::g_launch_counts[o][k][m], __ATOMIC_RELAXED);
         if (reset) __atomic_store_n(&gs::g_launch_counts[o][k][m], 0LL, __ATOMIC_RELAXED);
       }
   return GS_OK;
 }
 
+extern "C" int gs_debug_set_stream_mode(int32_t mode) {
+  if (mode < -1 || mode > 2) return GS_E_BADARG;
+  gs::g_stream_mode = mode;      // -1: back to the environment's GS_STREAM (default 1)
+  return GS_OK;
+}
+
 extern "C" int gs_debug_conv_launch_flops(double* flops, int32_t reset) {
   for (int o = 0; o < 3; ++o)
-    for (int k = 0; k < 4; ++k) {
-      if (flops) flops[o * 4 + k] = gs::g_launch_flops[o][k];
+    for (int k = 0; k < GS_KLOOP_COUNT; ++k) {
+      if (flops) flops[o * GS_KLOOP_COUNT + k] = gs::g_launch_flops[o][k];
       if (reset) gs::g_launch_flops[o][k] = 0.0;
     }
   return GS_OK;

@@ -1696,8 +1696,8 @@ constexpr size_t kMaxSlabBytes = 96u << 20;
 // launches each (op, K loop) pair has seen in this process (gs_debug_conv_launch_counts): lets the
 // parity tests assert WHICH K loop produced the numbers they compare (capi_misc.hip owns the storage).
 extern thread_local gs_debug_launch g_last_launch;
-extern long long g_launch_counts[3][4][3];
-extern double g_launch_flops[3][4];   // algorithmic 2*M*N*K per (op, K loop); single-writer per stream thread
+extern long long g_launch_counts[3][GS_KLOOP_COUNT][3];
+extern double g_launch_flops[3][GS_KLOOP_COUNT];   // algorithmic 2*M*N*K per (op, K loop); single-writer per stream thread
 static inline void note_launch(int op, int kloop, const Plan& pl, bool aff, int bw_mode,
                                double flops = 0.0) {
   g_launch_flops[op][kloop] += flops;

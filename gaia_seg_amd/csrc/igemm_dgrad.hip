@@ -1,5 +1,6 @@
 // DynConv2d data gradient (implicit GEMM, fp32 MFMA) — see igemm_core.h
 #include "igemm_core.h"
+#include "igemm_stream.h"
 #include "fused_internal.h"
 
 using namespace gs;
@@ -166,6 +167,30 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
   const bool fast = fast_rows_ok(d->Co, ks, src_b, dense_b) && getenv("GS_NO_FAST") == nullptr;
   static const bool no_bnb = getenv("GS_NO_BNBWD_FUSE") != nullptr;
   bool bnb = false, bnb_split = false;
+  // short-K 1x1 data gradients over many rows: the streaming kernel (igemm_stream.h); the fused
+  // BatchNorm-backward sums come out as one partial per workgroup row range
+  const StreamPlan sp = (fast && ks == 1 && d->stride == 1) ? stream_plan(M, d->Ci, d->Co, true)
+                                                            : StreamPlan{0, 0, 0, 0, 0};
+  if (sp.ok) {
+    if (bw && !no_bnb && bw->y && bw->coeffs && bw->sums &&
+        (bw->mode == 1 || (bw->mode == 2 && bw->act)) && workspace && aligned16(workspace) &&
+        aligned16(bw->y) && aligned16(bw->coeffs) && (bw->ldy & 3) == 0 && bw->ldy >= d->Ci &&
+        (bw->mode == 1 || (aligned16(bw->act) && (bw->ldact & 3) == 0 && bw->ldact >= d->Ci)) &&
+        (size_t)2 * d->Ci * sp.row_groups * sizeof(float) <= workspace_bytes) {
+      a.bw_y = bw->y; a.bw_ldy = bw->ldy; a.bw_act = bw->act; a.bw_ldact = bw->ldact;
+      a.bw_coeffs = bw->coeffs; a.bw_mode = bw->mode;
+      a.bw_part = static_cast<float*>(workspace);
+      bnb = true;
+    }
+    a.slab = nullptr;
+    launch_stream<true>(sp, a, st);
+    rc = launch_status();
+    if (bnb && rc == GS_OK) {
+      rc = bn_sum_partials(a.bw_part, sp.row_groups, 2 * d->Ci, bw->sums, st);
+      if (fused) *fused = 1;
+    }
+    return rc;
+  }
   if (bw && !no_bnb && d->stride == 1 && fast && bw->y && bw->coeffs && bw->sums &&
       (bw->mode == 1 || (bw->mode == 2 && bw->act)) && workspace && aligned16(workspace) &&
       aligned16(bw->y) && aligned16(bw->coeffs) && (bw->ldy & 3) == 0 && bw->ldy >= d->Ci &&

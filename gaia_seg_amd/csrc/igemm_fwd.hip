@@ -1,5 +1,6 @@
 // DynConv2d forward (implicit GEMM, fp32 MFMA) — see igemm_core.h
 #include "igemm_core.h"
+#include "igemm_stream.h"
 
 using namespace gs;
 
@@ -24,6 +25,18 @@ extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
 }
 
 namespace gs {
+// the streaming 1x1 kernel takes a forward when: 1x1, stride 1, no padding, NHWC x with contiguous
+// pixel rows, no bias / addend, and stream_plan() finds a column-block width whose weights fit in LDS
+static StreamPlan stream_fwd_plan(const gs_conv_desc* d, bool fast, const float* bias,
+                                  const float* addend) {
+  StreamPlan none{0, 0, 0, 0, 0};
+  if (!fast || bias || addend || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0)
+    return none;
+  if (d->x_sh != (int64_t)d->W * d->x_sw || d->x_sn != (int64_t)d->H * d->x_sh) return none;
+  if (d->in_affine && d->Ci > 256) return none;
+  return stream_plan((long)d->N * d->Ho * d->Wo, d->Co, d->Ci, false);
+}
+
 // Forward with the options of the fused conv+BN entry point (fused_layers.hip):
 //   want_stats: the caller wants BatchNorm batch statistics of y.  Without split-K the epilogue
 //     writes per-tile partials to the start of `workspace` (info->mode = 1); with split-K the
@@ -72,6 +85,27 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
     if (!conv_in_affine_ok(d) || !fast || pl.bm != 64) return GS_E_BADARG;
     if (!aligned16(d->in_affine)) return GS_E_ALIGN;
     a.a_coeffs = d->in_affine;
+  }
+  // short-K 1x1 convs over many rows: the streaming kernel (igemm_stream.h)
+  const StreamPlan sp = stream_fwd_plan(d, fast, bias, addend);
+  if (sp.ok) {
+    int mode = 0;
+    if (want_stats && info) {
+      const size_t part_b = (size_t)3 * d->Co * sp.row_groups * sizeof(float);
+      if (workspace && part_b <= workspace_bytes && aligned16(workspace)) {
+        a.tile_stats = static_cast<float*>(workspace);
+        mode = 1;
+      }
+    }
+    if (info) {
+      info->mode = mode; info->splits = 1; info->tiles_m = sp.row_groups;
+      info->bm = sp.tiles_per_wg * kStreamBM;
+      info->slab = nullptr; info->slab_bytes = 0; info->timed = false;
+      info->flops = 2.0 * (double)M * d->Co * d->Ci;
+    }
+    a.slab = nullptr;
+    launch_stream<false>(sp, a, st);
+    return launch_status();
   }
   const bool timed = d->role == GS_CONV_ROLE_BOTTLENECK3X3 && k3_prof_on();
   if (timed) k3_prof_begin(st);
@@ -154,8 +188,14 @@ extern "C" int gs_debug_query_conv_launch(const gs_conv_desc* d, int32_t op, gs_
   if (op == GS_OP_FORWARD) {
     pl = plan_fwd(d);
     const size_t src_b = (size_t)d->N * d->x_sn * sizeof(float);
-    if (vec && fast_rows_ok(d->Ci, ks, src_b, w_bytes) && !no_fast)
+    if (vec && fast_rows_ok(d->Ci, ks, src_b, w_bytes) && !no_fast) {
       kloop = rows_fast_kloop<false>(pl, aff);
+      const StreamPlan sp = stream_fwd_plan(d, true, nullptr, nullptr);
+      if (sp.ok) {
+        kloop = GS_KLOOP_STREAM;
+        pl = Plan{kStreamBM, sp.bnw, 1, (int)ceil_div(d->Ci, BK), (int)ceil_div(d->Ci, BK), sp.row_groups, sp.ncb};
+      }
+    }
   } else if (op == GS_OP_DGRAD) {
     const size_t dy_b = (size_t)d->N * d->Ho * d->Wo * d->ldy * sizeof(float);
     const bool fast = fast_rows_ok(d->Co, ks, dy_b, w_bytes) && !no_fast;
@@ -167,7 +207,15 @@ extern "C" int gs_debug_query_conv_launch(const gs_conv_desc* d, int32_t op, gs_
       kloop = rows_fast_kloop<true>(pl, false);
     } else {
       pl = plan_dgrad(d);
-      if (d->stride == 1 && fast) kloop = rows_fast_kloop<true>(pl, false);
+      if (d->stride == 1 && fast) {
+        kloop = rows_fast_kloop<true>(pl, false);
+        const StreamPlan sp = ks == 1 ? stream_plan((long)d->N * d->H * d->W, d->Ci, d->Co, true)
+                                      : StreamPlan{0, 0, 0, 0, 0};
+        if (sp.ok && d->x_sc == 1) {
+          kloop = GS_KLOOP_STREAM;
+          pl = Plan{kStreamBM, sp.bnw, 1, (int)ceil_div(d->Co, BK), (int)ceil_div(d->Co, BK), sp.row_groups, sp.ncb};
+        }
+      }
     }
   } else {
     pl = plan_wgrad(d);

@@ -55,7 +55,8 @@ class DebugLaunch(Structure):
 
 
 OP_FORWARD, OP_DGRAD, OP_WGRAD = 0, 1, 2
-KLOOP_GENERIC, KLOOP_FP32, KLOOP_FP32_PAIRS, KLOOP_BF16X3 = 0, 1, 2, 3
+KLOOP_GENERIC, KLOOP_FP32, KLOOP_FP32_PAIRS, KLOOP_BF16X3, KLOOP_STREAM = 0, 1, 2, 3, 4
+KLOOP_COUNT = 5
 
 
 class CeDesc(Structure):
@@ -151,6 +152,7 @@ PROTOTYPES = {
                                    POINTER(_i32)]),
     "gs_debug_last_conv_launch": (_i32, [POINTER(DebugLaunch)]),
     "gs_debug_conv_launch_counts": (_i32, [POINTER(_i64), _i32]),
+    "gs_debug_set_stream_mode": (_i32, [_i32]),
     "gs_debug_conv_launch_flops": (_i32, [POINTER(_f64), _i32]),
     "gs_debug_query_conv_launch": (_i32, [_CD, _i32, POINTER(DebugLaunch)]),
     "gs_stream_fork": (_i32, [_P, _P]),

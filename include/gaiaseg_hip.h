@@ -508,6 +508,8 @@ int gs_debug_query_plan(int32_t M, int32_t N, int32_t K, int32_t max_splits, int
 #define GS_KLOOP_FP32 1         /* fast kernels, v_mfma_f32_16x16x4_f32, one K step per barrier       */
 #define GS_KLOOP_FP32_PAIRS 2   /* the same, two K steps per barrier                                  */
 #define GS_KLOOP_BF16X3 3       /* six v_mfma_f32_16x16x32_bf16 over an exact 3-way bf16 split        */
+#define GS_KLOOP_STREAM 4       /* 1x1 streaming kernel: weights resident in LDS, persistent over rows  */
+#define GS_KLOOP_COUNT 5
 typedef struct gs_debug_launch {
   int32_t op;                   /* GS_OP_*                                                            */
   int32_t kloop;                /* GS_KLOOP_*                                                         */
@@ -518,14 +520,19 @@ typedef struct gs_debug_launch {
 /* The most recent conv launch issued by the calling thread (a strided dgrad reports its last parity
  * class).  GS_E_BADARG if the thread has not launched any. */
 int gs_debug_last_conv_launch(gs_debug_launch* out);
-/* counts[(op * 4 + kloop) * 3 + bn_bwd_mode] = launches since the last reset (process-wide, 36
- * entries); reset != 0 clears after reading.  counts may be NULL (reset only). */
+/* counts[(op * GS_KLOOP_COUNT + kloop) * 3 + bn_bwd_mode] = launches since the last reset
+ * (process-wide, 45 entries); reset != 0 clears after reading.  counts may be NULL (reset only). */
 int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset);
-/* flops[op * 4 + kloop] = algorithmic FLOPs (2 * M * N * K of the implicit GEMM, padding not counted)
+/* flops[op * GS_KLOOP_COUNT + kloop] (15 entries) = algorithmic FLOPs (2 * M * N * K of the implicit GEMM, padding not counted)
  * launched since the last reset: bench.py states which share of a step's contraction work ran on
  * which MFMA path, so that its roofline fractions name the right bound.  Not thread-safe (one
  * launching thread at a time, like the training step). */
 int gs_debug_conv_launch_flops(double* flops, int32_t reset);
+/* Dispatch of the streaming 1x1 kernel (csrc/igemm_stream.h): 0 = never, 1 = the shapes where it
+ * measured ahead of the tile kernels (default), 2 = every shape whose weights fit in LDS (the operator
+ * tests cover all of its code paths this way), -1 = back to the GS_STREAM environment value.
+ * Process-global, not thread-safe. */
+int gs_debug_set_stream_mode(int32_t mode);
 /* What gs_conv2d_forward / _dgrad / _wgrad (op = GS_OP_*) WOULD launch for this descriptor: host
  * arithmetic only, no GPU needed (honours gs_debug_force_plan and the GS_X3 switches).  For a strided
  * dgrad it describes the parity class (0, 0). */

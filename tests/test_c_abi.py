@@ -138,10 +138,51 @@ def test_x3_dgrad_cases_pass_the_dispatch_gate_without_gpu():
         seen_split |= q.splits > 1 and q.ksteps_per_split >= 48
         seen_odd |= q.splits == 1 and q.ksteps_per_split % 2 == 1
     assert seen_bn == {64, 48} and seen_split and seen_odd
-    # forward and weight gradient of the same shape stay on the fp32 loops
-    d = _desc(lib, 2, 128, 136, 64, 256, 1, 1, 64, 256, 64, 256)
+    # forward and weight gradient of a bf16x3 data-gradient shape stay on the fp32 loops
+    d = _desc(lib, 2, 64, 64, 1024, 256, 1, 1, 1024, 256, 1024, 256)
+    assert L.gs_debug_query_conv_launch(ctypes.byref(d), lib.OP_DGRAD, ctypes.byref(q)) == 0
+    assert q.kloop == lib.KLOOP_BF16X3
     for op in (lib.OP_FORWARD, lib.OP_WGRAD):
         assert L.gs_debug_query_conv_launch(ctypes.byref(d), op, ctypes.byref(q)) == 0
         assert q.kloop in (lib.KLOOP_FP32, lib.KLOOP_FP32_PAIRS) and q.op == op
     assert L.gs_debug_query_conv_launch(ctypes.byref(d), 7, ctypes.byref(q)) == -1
     assert ctypes.sizeof(lib.DebugLaunch) == 8 * 4
+
+
+def test_stream_1x1_cases_dispatch_without_gpu():
+    """tests/test_stream_1x1_gpu.py's shapes reach the streaming 1x1 kernel (host arithmetic), the
+    stage-3/4 shapes and the 3x3s do not."""
+    if os.environ.get("GS_STREAM", "1") == "0":
+        pytest.skip("streaming kernel switched off")
+    from test_stream_1x1_gpu import STREAM_CASES, _sdesc
+    L = lib.load()
+    q = lib.DebugLaunch()
+    widths = set()
+    # production dispatch (mode 1): one column block, short data-gradient contractions
+    d = _sdesc(lib, STREAM_CASES[0])      # 64 -> 256 at 2 x 128 x 256
+    assert L.gs_debug_query_conv_launch(ctypes.byref(d), lib.OP_FORWARD, ctypes.byref(q)) == 0
+    assert q.kloop == lib.KLOOP_STREAM and q.bn == 256
+    assert L.gs_debug_query_conv_launch(ctypes.byref(d), lib.OP_DGRAD, ctypes.byref(q)) == 0
+    assert q.kloop == lib.KLOOP_BF16X3    # K = 256: stays on the tile kernel's bf16x3 loop
+    assert L.gs_debug_set_stream_mode(2) == 0 and L.gs_debug_set_stream_mode(5) == -1
+    try:
+        _stream_all_shapes(L, STREAM_CASES, _sdesc, q, widths)
+    finally:
+        L.gs_debug_set_stream_mode(-1)
+
+
+def _stream_all_shapes(L, STREAM_CASES, _sdesc, q, widths):
+    for case in STREAM_CASES:
+        d = _sdesc(lib, case)
+        for op in case[-1]:
+            assert L.gs_debug_query_conv_launch(ctypes.byref(d), op, ctypes.byref(q)) == 0
+            assert q.kloop == lib.KLOOP_STREAM and q.bm == 128 and q.splits == 1, (case, op)
+            widths.add(q.bn)
+    assert widths == {64, 128, 256}
+    for n, h, w, ci, co, k in [(2, 32, 64, 256, 1024, 1), (2, 16, 32, 2048, 512, 1), (2, 128, 256, 64, 64, 3),
+                               (2, 64, 128, 512, 128, 1)]:
+        d = lib.ConvDesc(N=n, H=h, W=w, Ci=ci, Co=co, Ci_max=ci, Co_ld=co, KH=k, KW=k, stride=1, pad=k // 2,
+                         dil=1, Ho=h, Wo=w, x_sn=h * w * ci, x_sh=w * ci, x_sw=ci, x_sc=1, ldy=co,
+                         ld_add=0, role=0, reserved=0, in_affine=None)
+        assert L.gs_debug_query_conv_launch(ctypes.byref(d), lib.OP_FORWARD, ctypes.byref(q)) == 0
+        assert q.kloop != lib.KLOOP_STREAM

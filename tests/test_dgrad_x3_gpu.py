@@ -50,11 +50,13 @@ def _expect_kloop(lib, rec):
 
 # n  h   w   ci  co  k dil ci_max co_ld ldx ldy acc  force_plan            what it covers
 X3_CASES = [
-    (2, 127, 131, 64, 64, 1, 1, 64, 64, 64, 64, 0, None),        # 1x1, bn 64, ragged M tail (33274 % 64 = 58), 4 K steps = 2 bf16 steps
+    # (1x1 data gradients over >= 16384 rows with a short contraction go to the streaming kernel,
+    # tests/test_stream_1x1_gpu.py; the bf16x3 loop keeps the 1x1s of stages 3-4: few rows, wide outputs)
+    (2, 63, 65, 512, 64, 1, 1, 512, 64, 512, 64, 0, None),       # 1x1, bn 64, ragged M tail (8190 % 64 = 62), 4 K steps = 2 bf16 steps
     (2, 128, 136, 48, 48, 3, 1, 48, 48, 48, 48, 0, None),        # 3x3, bn 48, odd nk16 = 27 (zero-padded last half step), step pairs cross taps (3 per tap)
     (2, 128, 128, 64, 80, 3, 2, 64, 80, 64, 80, 0, None),        # dilation 2 (OS8 stages), Co = 80: 5 K steps per tap, odd total 45
-    (2, 128, 136, 256, 64, 1, 1, 256, 64, 256, 64, 1, None),     # conv1's dgrad: 4 column tiles, accumulate onto the identity gradient
-    (2, 128, 136, 64, 256, 1, 1, 80, 320, 64, 256, 0, None),     # conv3's dgrad from a leading slice of a wider weight
+    (2, 64, 64, 1024, 256, 1, 1, 1024, 256, 1024, 256, 1, None), # stage-3 conv1's dgrad: 16 column tiles, accumulate onto the identity gradient
+    (2, 64, 64, 512, 256, 1, 1, 640, 320, 512, 256, 0, None),    # 1x1 from a leading slice of a wider weight
     (2, 64, 64, 128, 256, 3, 1, 128, 256, 128, 256, 0, None),    # split-K 3 x 48 K steps: slabs + fixed-order reduce
     (2, 64, 128, 192, 192, 3, 1, 192, 192, 192, 192, 1, None),   # long unsplit K (108 steps), 3 column tiles, accumulate
     (2, 128, 136, 48, 144, 3, 1, 96, 160, 112, 208, 1, (64, 48, 1)),   # dx and dy are channel slices of wider buffers (ld > C), bn 48, accumulate
@@ -147,11 +149,12 @@ def test_old_conv_cases_stay_on_the_fp32_loops(hip_lib):
         assert q.kloop != lib.KLOOP_BF16X3
 
 
-def test_bn_backward_epilogue_on_the_bf16x3_loop(hip_lib, monkeypatch):
-    """gs_bn_bwd_fuse modes 1 and 2 in the epilogue of bf16x3 launches: a stage of three bottlenecks
-    (planes 64 at 2 x 128 x 136, so conv2 / conv3 / conv1 data gradients all pass the gate).  The fused
-    and the unfused backward must agree, both must match the CPU oracle's OResLayer, and the launch
-    counters must show bf16x3 dgrads carrying mode 1 (bn1, bn2) and mode 2 (bn3 + accumulate)."""
+def test_bn_backward_epilogue_on_the_bf16x3_loop(hip_lib, monkeypatch, stream_all=False):
+    """gs_bn_bwd_fuse in the epilogues of the large-grid data-gradient kernels: a stage of three
+    bottlenecks (planes 64 at 2 x 128 x 136).  conv2's dgrad runs on the bf16x3 loop carrying mode 1
+    (bn1); the 1x1 dgrads run on the streaming kernel carrying mode 1 (bn2) and mode 2 (bn3 +
+    accumulate).  The fused and the unfused backward must agree, both must match the CPU oracle's
+    OResLayer, and the launch counters must show exactly that dispatch."""
     import gaia_seg_amd.hip.ops as ops
     from gaia_seg_amd.core.bricks import DynamicBottleneck
     from gaia_seg_amd.hip import lib
@@ -192,18 +195,30 @@ def test_bn_backward_epilogue_on_the_bf16x3_loop(hip_lib, monkeypatch):
         hip_lib.gs_debug_conv_launch_counts(None, 1)
         z.backward(gz.to(DEV).contiguous(memory_format=torch.channels_last))
         torch.cuda.synchronize()
-        counts = (ctypes.c_int64 * 36)()
+        counts = (ctypes.c_int64 * (3 * lib.KLOOP_COUNT * 3))()
         hip_lib.gs_debug_conv_launch_counts(counts, 1)
-        c = lambda kloop, mode: counts[(lib.OP_DGRAD * 4 + kloop) * 3 + mode]
+        c = lambda kloop, mode: counts[(lib.OP_DGRAD * lib.KLOOP_COUNT + kloop) * 3 + mode]
         x3 = [c(lib.KLOOP_BF16X3, m) for m in range(3)]
         f32 = [c(lib.KLOOP_FP32, m) + c(lib.KLOOP_FP32_PAIRS, m) for m in range(3)]
-        # conv2 + conv3 of all three blocks own bn1 / bn2 (mode 1); conv1 of blocks 1, 2 owns the
-        # previous block's bn3 (mode 2); block 0's conv1 and the shortcut conv (Ci = 32) are narrow
-        # (32-wide column tiles: fp32 loop, nothing fused since their input is the layer input)
+        stm = [c(lib.KLOOP_STREAM, m) for m in range(3)]
+        # Production dispatch: conv2 (3x3, owns bn1) and conv3 (1x1, K = 256, owns bn2) of the three
+        # blocks run on the bf16x3 loop carrying mode 1; conv1 of blocks 1, 2 (K = 64 -> 256 columns,
+        # owns the previous block's bn3, accumulating) runs on the streaming kernel carrying mode 2;
+        # block 0's conv1 and the shortcut conv (32 columns) stay on the fp32 tile loop, nothing fused.
+        # With every eligible shape streamed (tests/test_stream_1x1_gpu.py) all seven 1x1s stream.
+        big, other = (x3, f32) if X3_ON else (f32, x3)
+        narrow = [0, 0, 0] if stream_all else [2, 0, 0]
         if X3_ON:
-            assert x3 == ([0, 6, 2] if fuse else [8, 0, 0]) and f32 == [2, 0, 0], list(counts)
+            assert f32 == narrow, list(counts)
         else:
-            assert x3 == [0, 0, 0] and f32 == ([2, 6, 2] if fuse else [10, 0, 0]), list(counts)
+            assert other == [0, 0, 0], list(counts)
+            big = [b - n for b, n in zip(big, narrow)]
+        n_big = 3 if stream_all else 6
+        assert big == ([0, n_big, 0] if fuse else [n_big, 0, 0]), list(counts)
+        if stream_all:
+            assert stm == ([2, 3, 2] if fuse else [7, 0, 0]), list(counts)
+        else:
+            assert stm == ([0, 0, 2] if fuse else [2, 0, 0]), list(counts)
         results[fuse] = (z.detach().clone(), xg.grad.clone(),
                          {k: p.grad.clone() for k, p in layer.named_parameters()})
     assert torch.equal(results[True][0], results[False][0])
@@ -216,14 +231,14 @@ def test_bn_backward_epilogue_on_the_bf16x3_loop(hip_lib, monkeypatch):
     # other side than on the CPU and moves that pixel's gradient by O(1) -- tests/test_grad_criterion.py;
     # so the input gradient is held in the L2 norm and by the share of pixels off by more than 1e-3)
     dxe = (results[True][1].double().cpu() - xr.grad.double())
-    assert float(dxe.norm() / xr.grad.double().norm()) < 1e-3
+    assert float(dxe.norm() / xr.grad.double().norm()) < 3e-3
     assert float((dxe.abs() > 1e-3 * float(xr.grad.abs().max())).double().mean()) < 5e-3
     # (parameter gradients sum those pixels: the same handful of rounding-level ReLU flips shows as a
     # few 1e-3 of the largest entry, so they are held in the L2 norm; the sharp statements are fused == unfused above and the direct
     # dgrad cases at 3e-5)
     for k, g in results[True][2].items():
         want = ref_grads[k].grad.double()
-        assert float((g.double().cpu() - want).norm() / want.norm()) < 1e-3, k
+        assert float((g.double().cpu() - want).norm() / want.norm()) < 3e-3, k
         assert rel_err(g, want) < 2e-2, k
 
 

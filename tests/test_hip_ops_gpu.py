@@ -521,7 +521,7 @@ DEFER_CASES = [
 
 
 @pytest.mark.parametrize("case", DEFER_CASES)
-def test_deferred_bn_relu_in_operand_loaders(hip_lib, case, monkeypatch):
+def test_deferred_bn_relu_in_operand_loaders(hip_lib, case, monkeypatch, cpu_norm="max"):
     import gaia_seg_amd.hip.ops as ops
     from gaia_seg_amd.core.bricks import DynamicBatchNorm2d, DynamicConv2d, conv_bn_act
     from gaia_seg_amd.hip.runtime import tape_function
@@ -573,9 +573,18 @@ def test_deferred_bn_relu_in_operand_loaders(hip_lib, case, monkeypatch):
         assert torch.equal(a, b)            # loader fusion == written-out activation, bit for bit
     z, dx, g_ca, g_baw, g_bab, g_cb, g_bbw, g_bbb = results[0]
     assert rel_err(z, z_ref) < 1e-4
-    assert rel_err(dx, xr.grad) < 3e-4
+    if cpu_norm == "l2":
+        # large cases (tests/test_stream_1x1_gpu.py: millions of activations): a ReLU within rounding
+        # of zero may fall on the other side than on the CPU and moves single entries by O(1e-2); the
+        # bitwise equality above is the sharp statement, the CPU comparison is held in the L2 norm
+        def err(a, b):
+            return float((a.double().cpu() - b.double()).norm() / b.double().norm())
+        tol = 3e-3
+    else:
+        err, tol = rel_err, 3e-4
+    assert err(dx, xr.grad) < tol
     for got, ref in zip((g_ca, g_baw, g_bab, g_cb, g_bbw, g_bbb), pr):
-        assert rel_err(got, ref.grad) < 3e-4
+        assert err(got, ref.grad) < tol
 
 
 # BatchNorm-backward reduction folded into the consumer's dgrad epilogue (gs_bn_bwd_fuse): a stage of
