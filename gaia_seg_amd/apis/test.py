@@ -36,6 +36,10 @@ def apply_bn_calibration(model, calib_cfg, phase):
             m.running_mean = None
             m.running_var = None
             m.track_running_stats = False
+            # DynamicBatchNorm2d caches one BNParams view per mode holding the OLD buffers (ops.conv_bn
+            # decides "batch statistics?" from that view): an eval forward before the calibration
+            # would otherwise keep normalising with the running statistics
+            m.__dict__.pop("_bnp_cache", None)
             n += 1
     return n
 

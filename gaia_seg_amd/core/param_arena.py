@@ -92,11 +92,14 @@ class ParamArena:
             self._range_cache[key] = merged
         return merged
 
-    def zero_grad(self, ranges=None):
-        """Clear gradients.  A no-op while ``grads_clean`` holds: the buffer starts at zero and every
+    def zero_grad(self, ranges=None, trust_clean=False):
+        """Clear gradients.  ``trust_clean`` (passed only by IterBasedRunner, which owns the
+        invariant): a no-op while ``grads_clean`` holds -- the buffer starts at zero and every
         sgd_step(zero_grad=True) clears what the step wrote, so a training loop that always follows
-        backward with such a step over the same ranges never needs the fill kernels."""
-        if self.grads_clean:
+        backward with such a step over the same ranges never needs the fill kernels.  Any other caller
+        (a manual train_step + backward in a test, a tool, a val workflow) gets a real clear: the flag
+        says nothing about gradients produced outside the runner."""
+        if trust_clean and self.grads_clean:
             return
         if ranges is None:
             self.flat_grad.zero_()

@@ -349,7 +349,7 @@ class IterBasedRunner:
                 continue
             for eager in ((True, False) if self.graph_stats["eager"] == 0 else (False,)):
                 self._write_hyper()
-                self.arena.zero_grad(self.active_ranges)
+                self.arena.zero_grad(self.active_ranges, trust_clean=True)
                 self.arena.grads_clean = False
                 self.reducer.begin(self.trainable_params, self.arch_key)
                 if eager:
@@ -380,7 +380,7 @@ class IterBasedRunner:
             self._replay_step(entry, data_batch)
             t3 = time.perf_counter() if prof is not None else 0.0
         else:
-            self.arena.zero_grad(self.active_ranges)   # (a no-op after a clearing optimizer step)
+            self.arena.zero_grad(self.active_ranges, trust_clean=True)   # (a no-op after a clearing optimizer step)
             self.arena.grads_clean = False             # backward is about to write gradients
             self.reducer.begin(self.trainable_params,
                                self.arch_key if self.arch_key != ("current",) else None)

@@ -53,6 +53,8 @@ extern "C" int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset) {
   return GS_OK;
 }
 
+extern "C" int gs_debug_num_cu(void) { return gs::num_cu(); }
+
 extern "C" int gs_debug_set_stream_mode(int32_t mode) {
   if (mode < -1 || mode > 2) return GS_E_BADARG;
   gs::g_stream_mode = mode;      // -1: back to the environment's GS_STREAM (default 1)

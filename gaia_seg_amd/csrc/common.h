@@ -11,7 +11,22 @@ namespace gs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;      // CDNA wavefront
-constexpr int kNumCU = 256;    // MI355X
+constexpr int kNumCUDefault = 256;   // MI355X (8 XCDs x 32 CUs)
+// Compute units of the current device (hipDeviceProp::multiProcessorCount), read once; the planners'
+// "workgroups per CU" arithmetic uses it.  Without a device (host-only planning queries in the build
+// container) the MI355X figure is assumed.
+inline int num_cu() {
+  static const int v = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      return prop.multiProcessorCount;
+    (void)hipGetLastError();
+    return kNumCUDefault;
+  }();
+  return v;
+}
 constexpr int kNumXCD = 8;
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -30,7 +45,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // (256 CUs x 8 blocks), never more than the work needs.
 inline int stream_grid(int64_t work_items, int block) {
   int64_t g = ceil_div(work_items, block);
-  const int64_t cap = static_cast<int64_t>(kNumCU) * 8;
+  const int64_t cap = static_cast<int64_t>(num_cu()) * 8;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
   return static_cast<int>(g);

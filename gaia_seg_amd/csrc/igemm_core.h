@@ -1713,7 +1713,7 @@ static int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 static bool wg_target_forced() { static const bool v = getenv("GS_WG_TARGET") != nullptr; return v; }
-static int wg_target() { static const int v = env_int("GS_WG_TARGET", 2 * kNumCU); return v; }
+static int wg_target() { static const int v = env_int("GS_WG_TARGET", 2 * num_cu()); return v; }
 static int dyn_lds() { static const int v = env_int("GS_DYN_LDS", 0); return v; }
 static int pair_min_ksteps() { static const int v = env_int("GS_PAIR_MIN", 16); return v; }
 static int min_ksteps() { static const int v = env_int("GS_MIN_KSTEPS", 4); return v; }
@@ -1764,7 +1764,7 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
       const long tiles = (long)pl.tiles_m * ceil_div(Nn, bn);
       for (int sp = 1; sp <= s_max; ++sp) {
         if (sp > 1 && (size_t)sp * M * Nn * sizeof(float) > kMaxSlabBytes) break;
-        const long rounds = ceil_div(tiles * sp, kNumCU);
+        const long rounds = ceil_div(tiles * sp, num_cu());
         const double occ = rounds == 1 ? 1.2 : (rounds == 2 ? 1.08 : 1.0);
         double cost = (double)rounds * ((double)ceil_div(pl.nk_total, sp) + 4.0) * (bn / 64.0) *
                       kEff[i] * occ;
@@ -1805,8 +1805,8 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
   // 28.0 us unsplit, FCN-head 3x3 188 vs 200 us with 16 instead of 8 splits).
   long target = wg_target();
   if (pipelined && !wg_target_forced()) {
-    const long s_hi = std::max<long>(1, ceil_div(2L * kNumCU, t128));
-    target = (pl.nk_total / s_hi >= 48) ? 2 * kNumCU : kNumCU;
+    const long s_hi = std::max<long>(1, ceil_div(2L * num_cu(), t128));
+    target = (pl.nk_total / s_hi >= 48) ? 2 * num_cu() : num_cu();
   }
   const long can_split = allow_split ? std::min<long>(max_splits, std::max(1, pl.nk_total / min_ksteps())) : 1;
   static const int force_bm = env_int("GS_FORCE_BM", 0);
@@ -1859,12 +1859,12 @@ static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
 // fill / drain (r01 A/B: s2..s4 3x3 and the head convs +3..7 %, s1 3x3 -3 % if paired).
 static inline bool pair_loop_ok(const Plan& pl) {
   return pl.nk_per_split >= pair_min_ksteps() &&
-         (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * kNumCU;
+         (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * num_cu();
 }
 static inline bool x3_grid_ok(const Plan& pl, int min_ksteps_) {
   return min_ksteps_ > 0 && pl.bm == 64 && pl.nk_per_split >= min_ksteps_ &&
          (pl.splits == 1 || pl.nk_per_split >= 48) &&
-         (long)pl.tiles_m * pl.tiles_n * pl.splits >= 2L * kNumCU;
+         (long)pl.tiles_m * pl.tiles_n * pl.splits >= 2L * num_cu();
 }
 template <bool BTRANS>
 static inline int rows_fast_kloop(const Plan& pl, bool in_affine) {
@@ -2037,7 +2037,7 @@ static inline void launch_reduce(const IgemmArgs& a, int splits, int rows_are_ta
     hipLaunchKernelGGL((splitk_reduce_kernel<false, 1>), dim3(stream_grid(total, 256)), dim3(256), 0,
                        st, a, splits, rows_are_taps);
   } else if (splits >= 48) {
-    const int grid = (int)std::min<long>(ceil_div(total, 4), (long)kNumCU * 16);
+    const int grid = (int)std::min<long>(ceil_div(total, 4), (long)num_cu() * 16);
     hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(grid), dim3(256), 0, st, a, splits,
                        rows_are_taps);
   } else {

@@ -79,12 +79,12 @@ static inline StreamPlan stream_plan(long M, int Nn, int Cs, bool dgrad) {
   sp.bnw = best;
   sp.ncb = (int)ceil_div(Nn, best);
   const int tiles = (int)ceil_div(M, kStreamBM);
-  int rg = std::max(1, kNumCU / sp.ncb);
+  int rg = std::max(1, num_cu() / sp.ncb);
   if (rg > tiles) rg = tiles;
   sp.tiles_per_wg = (int)ceil_div(tiles, rg);
   sp.row_groups = (int)ceil_div(tiles, sp.tiles_per_wg);
   // worth it only when every wave streams at least two strips through the resident weights
-  sp.ok = sp.tiles_per_wg >= 2 && (long)sp.row_groups * sp.ncb >= kNumCU / 2;
+  sp.ok = sp.tiles_per_wg >= 2 && (long)sp.row_groups * sp.ncb >= num_cu() / 2;
   // ... and where it measured ahead of the tile kernels (profiles/r03_conv1x1_stream.md, kernels
   // alone, 1024x512 bs 2): ONE column block, so that the activations are read exactly once (several
   // blocks re-read them per block: 0.75-0.9x), little column padding, and for data gradients only the

@@ -195,7 +195,7 @@ extern "C" int gs_slide_fuse(const gs_slide_desc* d, const int32_t* win_y, const
   a.rw = resize_scale(d->W, d->Wo, d->align_corners);
   const long total = (long)d->N * d->Ho * d->Wo;
   // one wave owns 64 consecutive pixels of an output row; plenty of blocks to fill 256 CUs
-  const int grid = (int)std::min<long>(ceil_div(total, 256), (long)kNumCU * 16);
+  const int grid = (int)std::min<long>(ceil_div(total, 256), (long)num_cu() * 16);
   hipStream_t st = as_stream(stream);
   if (d->Ho == d->H && d->Wo == d->W)
     hipLaunchKernelGGL(slide_fuse_kernel<false>, dim3(grid), dim3(256), 0, st, a, logits, probs_in,

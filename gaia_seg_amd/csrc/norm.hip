@@ -612,7 +612,7 @@ static int apply_grid(long rows, int C) {
   const int C4 = C >> 2;
   const int rpi = C4 <= 256 ? 256 / C4 : 1;
   long gx = ceil_div(rows, (long)rpi * 2);
-  const long cap = (long)kNumCU * 8;
+  const long cap = (long)num_cu() * 8;
   if (gx > cap) gx = cap;
   return (int)std::max<long>(gx, 1);
 }

@@ -472,7 +472,7 @@ static int avgpool_splits(int N, int H, int W, int C, int total_bins) {
   const int C4 = C >> 2;
   const int rpi = C4 <= 256 ? 256 / C4 : 1;
   const long blocks = (long)N * total_bins * (C4 <= 256 ? 1 : ceil_div(C4, 256));
-  long want = ceil_div(2 * kNumCU, blocks);
+  long want = ceil_div(2 * num_cu(), blocks);
   const long max_by_px = std::max<long>(1, ((long)H * W) / (8L * rpi));
   if (want > max_by_px) want = max_by_px;
   if (want > 32) want = 32;
@@ -587,7 +587,7 @@ extern "C" int gs_bilinear_forward(const float* x, int32_t N, int32_t Hi, int32_
 static int bilinear_bwd_splits(int N, int Hi, int Wi, int C, int Ho) {
   const long threads = (long)N * Hi * Wi * (C >> 2);
   const long rows_per_src = std::max<long>(1, (2L * Ho) / std::max(Hi, 1));  // footprint rows
-  long want = ceil_div((long)kNumCU * 256 * 2, threads);
+  long want = ceil_div((long)num_cu() * 256 * 2, threads);
   if (want > rows_per_src / 2) want = rows_per_src / 2;
   if (want > 32) want = 32;
   return (int)std::max<long>(want, 1);

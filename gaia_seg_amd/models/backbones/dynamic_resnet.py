@@ -38,48 +38,42 @@ class DynamicResNet(nn.Module, DynamicMixin):
                  stage_with_dcn=(False, False, False, False), plugins=None, with_cp=False,
                  zero_init_residual=True, contract_dilation=False):
         super().__init__()
-        self.stem_width, self.body_width = stem_width, body_width
-        self.num_stages = num_stages
-        assert 1 <= num_stages <= 4
-        self.strides, self.dilations = strides, dilations
-        assert len(strides) == len(dilations) == num_stages
-        self.out_indices = out_indices
-        assert max(out_indices) < num_stages
-        self.style, self.deep_stem, self.avg_down = style, deep_stem, avg_down
-        self.frozen_stages, self.frozen_layers = frozen_stages, frozen_layers
-        self.conv_cfg, self.norm_cfg, self.act_cfg = conv_cfg, norm_cfg, act_cfg
-        self.with_cp, self.norm_eval = with_cp, norm_eval
-        self.dcn, self.stage_with_dcn = dcn, stage_with_dcn
-        self.contract_dilation = contract_dilation
-        if dcn is not None:
-            assert len(stage_with_dcn) == num_stages
-            raise NotImplementedError("dcn is not used by the in-tree configs")
-        if plugins is not None:
-            raise NotImplementedError("plugins are not used by the in-tree configs")
-        self.plugins = plugins
-        self.zero_init_residual = zero_init_residual
+        # -- what the in-tree configs cannot ask for (reference asserts: dynamic_resnet.py:109-114) --
+        if not 1 <= num_stages <= 4:
+            raise AssertionError("num_stages must be in 1..4")
+        if not (len(strides) == len(dilations) == num_stages) or max(out_indices) >= num_stages:
+            raise AssertionError("strides / dilations / out_indices do not match num_stages")
+        if dcn is not None or plugins is not None:
+            raise NotImplementedError("dcn / plugins are not used by the in-tree seg configs")
+        # -- the constructor arguments stay readable under their own names (tools and hooks read them) --
+        for name, value in dict(
+                stem_width=stem_width, body_width=body_width, num_stages=num_stages, strides=strides,
+                dilations=dilations, out_indices=out_indices, style=style, deep_stem=deep_stem,
+                avg_down=avg_down, frozen_stages=frozen_stages, frozen_layers=frozen_layers,
+                conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg, with_cp=with_cp,
+                norm_eval=norm_eval, dcn=dcn, stage_with_dcn=stage_with_dcn, plugins=plugins,
+                zero_init_residual=zero_init_residual, contract_dilation=contract_dilation).items():
+            setattr(self, name, value)
         self.block = DynamicBottleneck  # the reference has no BasicBlock (dynamic_resnet.py:132-133)
-        self.body_depth = body_depth[:num_stages]
-        self.inplanes = stem_width[-1] if deep_stem else stem_width
+        self.body_depth = list(body_depth[:num_stages])
         self.init_state(stem={"width": stem_width}, body={"depth": body_depth, "width": body_width})
+
+        # -- modules, all at their MAXIMUM size; names fix the state_dict keys --
         self._make_stem_layer(in_channels, stem_width)
-
+        width_in = stem_width[-1] if deep_stem else stem_width
         self.res_layers = []
-        for i, num_blocks in enumerate(self.body_depth):
-            planes = body_width[i]
-            res_layer = self.make_res_layer(
-                block=self.block, inplanes=self.inplanes, planes=planes, depth=num_blocks,
-                stride=strides[i], dilation=dilations[i], style=self.style,
-                avg_down=self.avg_down, with_cp=with_cp, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
-                dcn=None, contract_dilation=contract_dilation, plugins=None)
-            self.inplanes = planes * self.block.expansion
-            layer_name = "layer%d" % (i + 1)
-            self.add_module(layer_name, res_layer)
-            self.res_layers.append(layer_name)
-
+        for stage, (depth, planes) in enumerate(zip(self.body_depth, body_width), start=1):
+            self.res_layers.append("layer%d" % stage)
+            self.add_module(self.res_layers[-1], self.make_res_layer(
+                block=self.block, inplanes=width_in, planes=planes, depth=depth,
+                stride=strides[stage - 1], dilation=dilations[stage - 1], style=style,
+                avg_down=avg_down, with_cp=with_cp, conv_cfg=conv_cfg, norm_cfg=norm_cfg, dcn=None,
+                contract_dilation=contract_dilation, plugins=None))
+            width_in = planes * self.block.expansion
+        self.inplanes = width_in
+        self.feat_dim = self.active_feat_dim = \
+            self.block.expansion * body_width[0] * 2 ** (len(self.body_depth) - 1)
         self._freeze_stages()
-        self.feat_dim = self.block.expansion * body_width[0] * 2 ** (len(self.body_depth) - 1)
-        self.active_feat_dim = self.feat_dim
 
     def make_res_layer(self, **kwargs):
         return DynamicResLayer(**kwargs)
@@ -89,22 +83,18 @@ class DynamicResNet(nn.Module, DynamicMixin):
         return getattr(self, self.norm1_name)
 
     def _make_stem_layer(self, in_channels, stem_width):
-        # dynamic_resnet.py:255-302
+        # Stem (dynamic_resnet.py:255-302).  Deep stem: three 3x3 conv + norm + ReLU triples in ONE
+        # Sequential, so the convs sit at indices 0 / 3 / 6 and the norms at 1 / 4 / 7 (the indices
+        # manipulate_stem relies on and the checkpoint keys "stem.0.weight" ...); else the 7x7 conv.
         if self.deep_stem:
-            assert isinstance(stem_width, Sequence)
-            self.stem = nn.Sequential(
-                build_conv_layer(self.conv_cfg, in_channels, stem_width[0], kernel_size=3, stride=2,
-                                 padding=1, bias=False),
-                build_norm_layer(self.norm_cfg, stem_width[0])[1],
-                nn.ReLU(inplace=True),
-                build_conv_layer(self.conv_cfg, stem_width[0], stem_width[1], kernel_size=3,
-                                 stride=1, padding=1, bias=False),
-                build_norm_layer(self.norm_cfg, stem_width[1])[1],
-                nn.ReLU(inplace=True),
-                build_conv_layer(self.conv_cfg, stem_width[1], stem_width[2], kernel_size=3,
-                                 stride=1, padding=1, bias=False),
-                build_norm_layer(self.norm_cfg, stem_width[2])[1],
-                nn.ReLU(inplace=True))
+            assert isinstance(stem_width, Sequence) and len(stem_width) == 3
+            mods, cin = [], in_channels
+            for i, cout in enumerate(stem_width):
+                mods += [build_conv_layer(self.conv_cfg, cin, cout, kernel_size=3,
+                                          stride=2 if i == 0 else 1, padding=1, bias=False),
+                         build_norm_layer(self.norm_cfg, cout)[1], nn.ReLU(inplace=True)]
+                cin = cout
+            self.stem = nn.Sequential(*mods)
         else:
             self.conv1 = build_conv_layer(self.conv_cfg, in_channels, stem_width, kernel_size=7,
                                           stride=2, padding=3, bias=False)

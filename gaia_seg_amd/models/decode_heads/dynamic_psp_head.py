@@ -85,7 +85,14 @@ class DynamicPSPHead(DynamicBaseDecodeHead):
     def losses(self, seg_logit, seg_label):
         loss = super().losses(seg_logit, seg_label)
         if self.keep_resize_logit:
-            import torch.nn.functional as F
-            loss["resize_logit"] = F.interpolate(seg_logit, size=seg_label.shape[2:],
-                                                 mode="bilinear", align_corners=self.align_corners)
+            # the full-resolution logits of dynamic_psp_head.py:152-160, through the HIP resize kernel
+            # (gs_bilinear_forward) like every other resize of the path; a log variable only
+            from ...core.inference import _padded_nhwc
+            from ...hip import ops
+            from ...hip.runtime import Act, Tape
+            c = seg_logit.shape[1]
+            h, w = seg_label.shape[2:]
+            src = Act(_padded_nhwc(seg_logit), False)      # class stride padded to a float4 multiple
+            up = ops.bilinear(Tape(enabled=False), src, (int(h), int(w)), self.align_corners)
+            loss["resize_logit"] = up.as_nchw()[:, :c]
         return loss

@@ -528,6 +528,9 @@ int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset);
  * which MFMA path, so that its roofline fractions name the right bound.  Not thread-safe (one
  * launching thread at a time, like the training step). */
 int gs_debug_conv_launch_flops(double* flops, int32_t reset);
+/* Compute units the planners assume: hipDeviceProp::multiProcessorCount of the current device, read
+ * once at first use (256 on an MI355X; 256 is also assumed when no device is present). */
+int gs_debug_num_cu(void);
 /* Dispatch of the streaming 1x1 kernel (csrc/igemm_stream.h): 0 = never, 1 = the shapes where it
  * measured ahead of the tile kernels (default), 2 = every shape whose weights fit in LDS (the operator
  * tests cover all of its code paths this way), -1 = back to the GS_STREAM environment value.

@@ -178,10 +178,35 @@ def test_bn_calibration_switches():
     assert apply_bn_calibration(net, dict(reset_stats=True), "test") == 0      # wrong phase: no-op
     assert apply_bn_calibration(net, dict(reset_stats=True), "train") == 2
     assert float(net[0].running_mean.abs().max()) == 0.0 and float((net[2].running_var - 1).abs().max()) == 0.0
+    # an eval forward BEFORE the calibration fills the per-mode BNParams cache with the running
+    # buffers; the calibration must drop it, or the BN keeps normalising with the old statistics
+    net.eval()
+    assert net[0].bn_params(8).running_mean is not None and "_bnp_cache" in net[0].__dict__
     assert apply_bn_calibration(net, dict(use_minibatch_stats=True), "test") == 2
     assert net[0].running_mean is None and net[0].track_running_stats is False
+    assert "_bnp_cache" not in net[0].__dict__
     # eval-mode BN without running statistics normalises with the batch it sees
     assert net[0].eval().bn_params(8).running_mean is None
+
+
+def test_arena_zero_grad_clears_unless_the_runner_vouches_for_it():
+    """ParamArena.zero_grad skips the fill only for the caller that owns the "gradients are clean"
+    invariant (IterBasedRunner: trust_clean=True); any other caller gets a real clear even while the
+    flag is set (a manual backward outside the runner must not leak stale gradients)."""
+    import torch
+    from gaia_seg_amd.core.param_arena import ParamArena
+    arena = ParamArena.__new__(ParamArena)        # (the constructor needs the GPU; zero_grad does not)
+    arena.flat_grad = torch.full((256,), 3.0)
+    arena.grads_clean = True
+    arena.zero_grad(trust_clean=True)
+    assert float(arena.flat_grad.abs().max()) == 3.0            # the runner's no-op
+    first = [(0, 64), (128, 192)]
+    arena.zero_grad(first)
+    for a, b in first:
+        assert float(arena.flat_grad[a:b].abs().max()) == 0.0   # only the ranges asked for
+    assert float(arena.flat_grad.abs().max()) == 3.0
+    arena.zero_grad()
+    assert float(arena.flat_grad.abs().max()) == 0.0
 
 
 def test_train_pipeline_random_decisions_follow_the_cpu_transforms():
