@@ -446,6 +446,7 @@ def main():
             rec[0], rec[1] = 0, 0.0
     arch_log_start = runner.iter
     bytes0 = reducer.bytes_reduced
+    reducer.collectives = 0
     prof = None
     if os.environ.get("GS_CPROFILE"):   # diagnostics: host profile of the timed loop (main thread)
         import cProfile
@@ -458,6 +459,8 @@ def main():
     kl = (ctypes.c_double * 15)()
     L.gs_debug_conv_launch_flops(kl, 1)              # which MFMA path carried the first pass's FLOPs
     seg_new = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0) - seg0
+    bytes_per_step = (reducer.bytes_reduced - bytes0) / max(args.steps, 1)
+    collectives_per_step = reducer.collectives / max(args.steps, 1) if world > 1 else 0.0
     for _ in range(max(args.repeats, 1) - 1):        # same K draws again (the weights keep training)
         passes.append(timed_pass(False))
     elapsed = sorted(passes)[len(passes) // 2]       # the median pass: exactly K timed steps
@@ -469,8 +472,7 @@ def main():
         if _rt.BACKWARD_PROFILE is not None:
             print("---- backward thread ----", file=sys.stderr)
             pstats.Stats(_rt.BACKWARD_PROFILE, stream=sys.stderr).sort_stats("tottime").print_stats(30)
-    bytes_per_step = (reducer.bytes_reduced - bytes0) / max(args.steps, 1)
-    arch_log_end = runner.iter
+    arch_log_end = arch_log_start + args.steps
     loss = float(runner.outputs["loss"].detach())
     if runner.host_prof:
         hp = runner.host_prof
@@ -518,6 +520,7 @@ def main():
                 "global_batch": world * bs,
                 "parallelism": "dp%d" % world,
                 "allreduce_bytes_per_step_per_rank": int(bytes_per_step),
+                "allreduce_launches_per_step": round(collectives_per_step, 1),
                 "last_loss": round(loss, 5),
                 "passes": {"repeats": len(passes), "value_is": "median pass",
                            "images_per_sec_min": round(imgs / max(passes), 3),

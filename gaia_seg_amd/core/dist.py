@@ -110,12 +110,17 @@ class GradReducer:
     """Bucketed all-reduce over slices of a flat gradient buffer, driven by per-parameter
     'gradient ready' notifications from the backward tape."""
 
-    def __init__(self, flat_grad, segments, bucket_bytes=64 << 20, group=None):
-        """flat_grad: 1-D tensor; segments: {id(param): (offset, numel)} (ParamArena.segments)."""
+    def __init__(self, flat_grad, segments, bucket_bytes=64 << 20, group=None, hole_frac=0.05):
+        """flat_grad: 1-D tensor; segments: {id(param): (offset, numel)} (ParamArena.segments).
+        hole_frac: holes inside a bucket (parameters of depth-skipped blocks: their gradient stays
+        zero on every rank) are reduced along with it while they add up to less than this share of
+        the bucket -- one collective for the bucket instead of one per contiguous run."""
         self.flat_grad = flat_grad
         self.segments = segments
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
         self.group = group
+        self.hole_frac = hole_frac
+        self.collectives = 0          # launches handed to the backend (a coalesced group counts once)
         self._plans = {}
         self._active = None
         self._works = []
@@ -147,10 +152,35 @@ class GradReducer:
                     runs[-1][1] = o + n
                 else:
                     runs.append([o, o + n])
-            plan.append(dict(param_ids=[id(p) for _, _, p in b], runs=[tuple(r) for r in runs]))
+            plan.append(dict(param_ids=[id(p) for _, _, p in b],
+                             runs=self.pad_holes([tuple(r) for r in runs], self.hole_frac)))
         if key is not None:
             self._plans[key] = plan
         return plan
+
+    @staticmethod
+    def pad_holes(runs, hole_frac):
+        """Merge neighbouring runs of one bucket across small holes: smallest hole first, while the
+        holes swallowed so far stay below hole_frac of the bucket's payload.  (The holes hold the
+        gradients of parameters the sampled subnet does not use: zero on every rank, and the optimizer
+        never touches them, so summing them changes nothing.)"""
+        runs = sorted(runs)
+        payload = sum(b - a for a, b in runs)
+        budget = int(hole_frac * payload)
+        holes = sorted((runs[i + 1][0] - runs[i][1], i) for i in range(len(runs) - 1))
+        take, used = set(), 0
+        for size, i in holes:
+            if used + size > budget:
+                break
+            take.add(i)
+            used += size
+        out = []
+        for i, (a, b) in enumerate(runs):
+            if out and (i - 1) in take:
+                out[-1] = (out[-1][0], b)
+            else:
+                out.append((a, b))
+        return out
 
     def begin(self, params, key=None):
         """Arm the reducer for one backward pass over ``params`` (the active subnet)."""
@@ -206,16 +236,36 @@ class GradReducer:
         else:
             self._issue(runs)
 
+    def _coalescing(self):
+        """RCCL can take a bucket's runs as ONE grouped launch (ncclGroupStart / End behind
+        ProcessGroupNCCL.allreduce_coalesced, reached through torch's coalescing manager); gloo cannot
+        coalesce device tensors, so every other backend keeps one call per run."""
+        if not self.flat_grad.is_cuda:
+            return False
+        try:
+            return dist.get_backend(self.group) == "nccl"
+        except Exception:
+            return False
+
     def _issue(self, runs):
-        """All-reduce one bucket: one call per contiguous run (a bucket is a single arena range
-        unless depth-skipped blocks left holes in it).  Grouping the runs into one coalesced call
-        was tried (torch's private _coalescing_manager): gloo cannot coalesce device tensors, and an
-        RCCL-only branch could not be exercised on a one-GPU box, so the tested form stays."""
-        for a, b in runs:
-            t = self.flat_grad[a:b]
+        """All-reduce one bucket.  A bucket is a single arena range unless depth-skipped blocks left
+        holes too large to pad (pad_holes); several runs go out as one grouped RCCL launch where the
+        backend supports it (tests/test_ddp_gpu.py exercises that branch on a one-rank RCCL group),
+        else as one call per run."""
+        tensors = [self.flat_grad[a:b] for a, b in runs]
+        self.bytes_reduced += sum(t.numel() * t.element_size() for t in tensors)
+        if len(tensors) > 1 and self._coalescing():
+            from torch.distributed.distributed_c10d import _coalescing_manager
+            with _coalescing_manager(group=self.group, async_ops=True) as cm:
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._works.append(cm)
+            self.collectives += 1
+            return
+        for t in tensors:
             self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
-            self.bytes_reduced += t.numel() * t.element_size()
+            self.collectives += 1
 
     def finish(self):
         """Flush buckets whose parameters never reported (no gradient this step) and wait."""

@@ -1768,7 +1768,8 @@ static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits 
         const double occ = rounds == 1 ? 1.2 : (rounds == 2 ? 1.08 : 1.0);
         double cost = (double)rounds * ((double)ceil_div(pl.nk_total, sp) + 4.0) * (bn / 64.0) *
                       kEff[i] * occ;
-        if (sp > 1) cost += (2.0 * sp + 1.0) * (double)M * (double)Nn * 1.4e-6;
+        static const double slab_cost = 1.4e-6 * env_int("GS_SLAB_COST_PCT", 100) / 100.0;
+        if (sp > 1) cost += (2.0 * sp + 1.0) * (double)M * (double)Nn * slab_cost;
         if (cost < best_cost - 1e-9) { best_cost = cost; best_bn = bn; best_s = sp; }
       }
     }

@@ -1,7 +1,8 @@
 """Two-rank data-parallel training on ONE MI355X (gloo process group over device tensors): the
 N>1 code path end to end — arch broadcast, bucketed all-reduce of the active gradient ranges driven
 by the backward tape, SyncBN statistics exchange in the heads, 1/world folded into the fused SGD.
-(RCCL needs one GPU per rank, so the real backend runs only in the driver's multi-GPU bench.)"""
+RCCL needs one GPU per rank: a two-rank RCCL test runs when two GPUs are visible, and a ONE-rank RCCL
+group exercises the backend-specific branch of the reducer (the grouped launch of a bucket's runs)."""
 import os
 import socket
 import sys
@@ -188,3 +189,43 @@ def test_two_ranks_over_rccl_match_the_gloo_run():
     g0, _ = _spawn("SyncBN")
     assert n0[3] == g0[3]
     assert abs(n0[1] - g0[1]) <= 1e-6 * g0[2] and abs(n0[2] - g0[2]) <= 1e-6 * g0[2]
+
+
+def _one_rank_rccl(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from gaia_seg_amd.core.dist import GradReducer
+        flat = torch.arange(4096, dtype=torch.float32, device="cuda")
+        want = flat.clone()
+        red = GradReducer(flat, {}, bucket_bytes=1 << 20)
+        assert red._coalescing()
+        runs = [(0, 512), (1024, 1536), (3072, 4096)]
+        red._issue(runs)                       # three runs -> ONE grouped RCCL launch
+        assert red.collectives == 1 and len(red._works) == 1
+        red._issue([(2048, 2560)])             # a single run: the plain call
+        assert red.collectives == 2
+        for w in red._works:
+            w.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(flat, want)         # the sum over one rank
+        assert red.bytes_reduced == 4 * (512 + 512 + 1024 + 512)
+        dist.destroy_process_group()
+        q.put("ok")
+    except BaseException as e:   # noqa: BLE001
+        q.put("%s: %s" % (type(e).__name__, e))
+        raise
+
+
+def test_bucket_runs_go_out_as_one_grouped_rccl_launch():
+    """The RCCL branch of GradReducer._issue (torch's coalescing manager -> ProcessGroupNCCL
+    allreduce_coalesced) on a one-rank RCCL group: RCCL has never run anywhere else in this
+    pipeline (no multi-GPU node so far), so at least the API path is executed on real hardware."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_rccl, args=(_free_port(), q))
+    p.start()
+    p.join(180)
+    assert not p.is_alive()
+    assert q.get(timeout=5) == "ok"

@@ -148,6 +148,30 @@ def test_grad_reducer_plan_covers_active_ranges_once():
     red.finish()                                               # ... and nothing to wait for
 
 
+def test_grad_reducer_pads_small_holes_into_one_collective():
+    """Depth-skipped blocks leave holes in a bucket; holes worth < 5 % of the bucket are reduced along
+    with it (their gradients are zero on every rank), smallest first, so the bucket is one collective."""
+    from gaia_seg_amd.core.dist import GradReducer
+    pad = GradReducer.pad_holes
+    assert pad([(0, 1000)], 0.05) == [(0, 1000)]
+    assert pad([(0, 1000), (1010, 2000)], 0.05) == [(0, 2000)]                  # hole 10 of 1990
+    assert pad([(0, 1000), (1200, 2000)], 0.05) == [(0, 1000), (1200, 2000)]    # hole 200 > 90
+    # the budget is shared: holes 30 + 40 fit into 5 % of 1930, the third (60) does not
+    assert pad([(0, 500), (530, 1000), (1040, 1500), (1560, 2060)], 0.05) == [(0, 1500), (1560, 2060)]
+    assert pad([(600, 700), (0, 500)], 0.0) == [(0, 500), (600, 700)]
+    # through the planner: a 16-element skipped parameter inside a 1-bucket plan
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (512, 16, 512)]
+    segs, off = {}, 0
+    for p in params:
+        segs[id(p)] = (off, p.numel())
+        off += p.numel()
+    red = GradReducer(torch.zeros(off), segs, bucket_bytes=1 << 20)
+    assert red._plan([params[0], params[2]], key=None)[0]["runs"] == [(0, 1040)]
+    red0 = GradReducer(torch.zeros(off), segs, bucket_bytes=1 << 20, hole_frac=0.0)
+    assert red0._plan([params[0], params[2]], key=None)[0]["runs"] == [(0, 512), (528, 1040)]
+    assert not red._coalescing()      # CPU tensors / no process group: one call per run
+
+
 def test_closed_form_flops_match_baseline_table(psp_model):
     """BASELINE.md §2 (OS32, 512x1024, per image): backbone GF (3x3 part) and params."""
     from gaia_seg_amd.core.flops import model_flops
