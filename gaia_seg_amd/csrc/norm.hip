@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // (a) conv without split-K: the conv epilogue wrote per-tile partials {s1, s2, shift} (quad-major,
 //     igemm_core.h rows_epilogue).  Merge the tiles exactly (Chan et al.): tile mean
 //     m_t = shift_t + s1_t/n_t, tile M2_t = s2_t - s1_t^2/n_t; mean = sum n_t m_t / N,
-//     M2 = sum [M2_t + n_t (m_t - mean)^2].  Two fixed-order block sums in double.
+//     M2 = sum [M2_t + n_t (m_t - mean)^2] -- evaluated in one pass around a common reference (see
+//     the kernel).  Fixed-order block sums in double.
 __device__ __forceinline__ void block_sum_d4(double (&a)[4], double* sh /* [16] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -409,39 +410,37 @@ __global__ __launch_bounds__(256) void bn_tile_finalize_kernel(
   // in this kernel: the compiler would move it to LDS, address it with the flat work-item id, and
   // fetch the workgroup size from the dispatch packet in HOST memory in every wave (measured:
   // 30 us instead of 5 for 512 workgroups).
-  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  // ONE pass over the partials (r03; two dependent passes -- means first, then M2 around the means --
+  // cost two L2 / fabric round trips in a kernel that is nothing but latency): every tile's sums are
+  // re-centred on a common reference r = tile 0's shift (a sample of the channel, so |r - mean| is a
+  // few standard deviations at most):  sum (v - r) = s1 + n d,  sum (v - r)^2 = s2 + 2 d s1 + n d^2
+  // with d = shift_t - r, accumulated in double; mean = r + S1 / M, M2 = S2 - S1^2 / M.
+  const f32x4 ref4 = shp[0];
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
   for (int p = t; p < np; p += 256) {
     const double n = (double)(p == np - 1 ? n_last : bm);
-    const f32x4 s1 = s1p[p], shv = shp[p];
-    a0 += n * (double)shv[0] + (double)s1[0];   // n_t * m_t
-    a1 += n * (double)shv[1] + (double)s1[1];
-    a2 += n * (double)shv[2] + (double)s1[2];
-    a3 += n * (double)shv[3] + (double)s1[3];
+    const f32x4 s1 = s1p[p], s2 = s2p[p], shv = shp[p];
+#define GS_ACC(E, A, B)                                              \
+    {                                                                \
+      const double d = (double)shv[E] - (double)ref4[E];             \
+      A += (double)s1[E] + n * d;                                    \
+      B += (double)s2[E] + d * (2.0 * (double)s1[E] + n * d);        \
+    }
+    GS_ACC(0, a0, b0) GS_ACC(1, a1, b1) GS_ACC(2, a2, b2) GS_ACC(3, a3, b3)
+#undef GS_ACC
   }
   {
     double a[4] = {a0, a1, a2, a3};
     block_sum_d4(a, sh);
-    a0 = a[0] * inv_M; a1 = a[1] * inv_M; a2 = a[2] * inv_M; a3 = a[3] * inv_M;   // means
-  }
-  double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-  for (int p = t; p < np; p += 256) {
-    const double n = (double)(p == np - 1 ? n_last : bm);
-    const double inv_n = p == np - 1 ? inv_last : inv_full;
-    const f32x4 s1 = s1p[p], s2 = s2p[p], shv = shp[p];
-#define GS_M2(E, MEAN, ACC)                                        \
-    {                                                              \
-      const double d1 = (double)s1[E] * inv_n;                     \
-      const double dm = (double)shv[E] + d1 - MEAN;                \
-      ACC += ((double)s2[E] - (double)s1[E] * d1) + n * dm * dm;   \
-    }
-    GS_M2(0, a0, b0) GS_M2(1, a1, b1) GS_M2(2, a2, b2) GS_M2(3, a3, b3)
-#undef GS_M2
-  }
-  {
     double b[4] = {b0, b1, b2, b3};
     block_sum_d4(b, sh);
-    b0 = b[0]; b1 = b[1]; b2 = b[2]; b3 = b[3];
+    // b <- M2, a <- mean
+    b0 = b[0] - a[0] * a[0] * inv_M; b1 = b[1] - a[1] * a[1] * inv_M;
+    b2 = b[2] - a[2] * a[2] * inv_M; b3 = b[3] - a[3] * a[3] * inv_M;
+    a0 = (double)ref4[0] + a[0] * inv_M; a1 = (double)ref4[1] + a[1] * inv_M;
+    a2 = (double)ref4[2] + a[2] * inv_M; a3 = (double)ref4[3] + a[3] * inv_M;
   }
+  (void)inv_full; (void)inv_last;
   if (t == 0) {
     const int c0 = q * 4;
 #define GS_FIN(E, MU, M2)                                                                        \
