@@ -20,6 +20,8 @@ sizes / mode / align_corners, the top-down add order of the FPN, dropout -> conv
      (+ _transform_inputs / cls_seg of the in-tree base copy dynamic_decode_head.py)
   FCNHead._transform_inputs / cls_seg        gaiaseg/models/decode_heads/fcn_head.py:179-202,248-253
   DynamicFCNHead.forward                     gaiaseg/models/decode_heads/dynamic_fcn_head.py:128-135
+  DynamicFCNHead.losses / DynamicPSPHead.losses   dynamic_fcn_head.py:137-159, dynamic_psp_head.py:149-173
+     (with the reference's own cross_entropy / weight_reduce_loss / accuracy)
 
 Fixture: for every case the state_dict of the stand-ins (keys = the reference's module names), the
 seeded inputs, the outputs, and the call trace [(child name, input shape, extra args)] incl. every
@@ -379,6 +381,73 @@ def case_fcn(out, meta, gen):
     meta["fcn"] = cases
 
 
+def _load_file(path, name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def case_losses(out, meta, gen):
+    """`losses` of DynamicFCNHead (dynamic_fcn_head.py:137-159) and DynamicPSPHead
+    (dynamic_psp_head.py:149-173): resize -> (sampler) -> squeeze -> loss_decode -> accuracy, run with
+    the reference's OWN cross_entropy (losses/cross_entropy_loss.py:67-94), weight_reduce_loss and
+    accuracy.  loss_decode is mmseg's CrossEntropyLoss [3P]: its forward is restated here as
+    loss_weight * cross_entropy(score, label, weight, class_weight=..., reduction='mean',
+    avg_factor=None, ignore_index=...)."""
+    utils = _load_file(os.path.join(REF, "gaiaseg/models/losses/utils.py"), "ref_loss_utils3")
+    acc = _load_file(os.path.join(REF, "gaiaseg/models/losses/accuracy.py"), "ref_accuracy3")
+    with open(os.path.join(REF, "gaiaseg/models/losses/cross_entropy_loss.py")) as f:
+        tree = ast.parse(f.read())
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "cross_entropy")
+    ns = dict(torch=torch, F=F, weight_reduce_loss=utils.weight_reduce_loss)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "cross_entropy_loss.py", "exec"), ns)
+    ref_ce = ns["cross_entropy"]
+    cases = []
+    for tag, head_kind, n, c, h, w, size, align, lw, use_sampler, cw in [
+            ("a", "fcn", 2, 19, 8, 16, (64, 128), False, 1.0, False, False),
+            ("b", "fcn", 2, 19, 5, 7, (33, 41), False, 0.4, True, False),     # aux-head weight, OHEM-style weights
+            ("c", "psp", 1, 5, 6, 6, (24, 24), True, 1.0, False, True),       # align_corners, class weights
+            ("d", "psp", 2, 19, 4, 8, (32, 64), False, 1.0, True, False)]:
+        trace = Trace()
+        rel = ("gaiaseg/models/decode_heads/dynamic_fcn_head.py", "DynamicFCNHead") if head_kind == "fcn" \
+            else ("gaiaseg/models/decode_heads/dynamic_psp_head.py", "DynamicPSPHead")
+        losses = _extract(rel[0], "losses", rel[1],
+                          dict(dict=dict, resize=_resize_recorder(trace), accuracy=acc.accuracy))
+        logits = torch.randn(n, c, h, w, generator=gen) * 2
+        label = torch.randint(0, c, (n, 1) + size, generator=gen)
+        label[:, :, :2] = 255
+        label[0, 0, 5:9, 3:8] = 255
+        pw = (torch.rand((n,) + size, generator=gen) > 0.35).float()
+        class_w = (torch.rand(c, generator=gen) + 0.5) if cw else None
+
+        class Sampler:
+            def sample(self, seg_logit, seg_label):
+                trace.note("sampler.sample", seg_logit, list(seg_label.shape))
+                return pw
+
+        def loss_decode(cls_score, lab, weight=None, ignore_index=-100):
+            trace.note("loss_decode", cls_score, list(lab.shape), weight is not None, int(ignore_index))
+            return lw * ref_ce(cls_score, lab, weight, class_weight=class_w, reduction="mean",
+                               avg_factor=None, ignore_index=ignore_index)
+        fk = types.SimpleNamespace(align_corners=align, sampler=Sampler() if use_sampler else None,
+                                   loss_decode=loss_decode, ignore_index=255)
+        res = losses(fk, logits, label)
+        out["losses_%s_logits" % tag] = logits.numpy()
+        out["losses_%s_label" % tag] = label.numpy()
+        out["losses_%s_pixel_weight" % tag] = pw.numpy()
+        if cw:
+            out["losses_%s_class_weight" % tag] = class_w.numpy()
+        out["losses_%s_loss_seg" % tag] = res["loss_seg"].numpy()
+        out["losses_%s_acc_seg" % tag] = res["acc_seg"].numpy()
+        cases.append(dict(tag=tag, head=head_kind, align_corners=align, loss_weight=lw,
+                          sampler=use_sampler, class_weight=cw, keys=sorted(res.keys()),
+                          resize_logit_shape=list(res["resize_logit"].shape) if "resize_logit" in res else None,
+                          trace=list(trace)))
+    meta["losses"] = cases
+
+
 def main():
     torch.manual_seed(0)
     gen = torch.Generator().manual_seed(20240)
@@ -388,6 +457,7 @@ def main():
     case_psp(out, meta, gen)
     case_uper(out, meta, gen)
     case_fcn(out, meta, gen)
+    case_losses(out, meta, gen)
     np.savez_compressed(os.path.join(HERE, "ref_wiring.npz"), **out)
     with open(os.path.join(HERE, "ref_wiring.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -178,3 +178,31 @@ def test_fcn_head_wiring(wiring):
                         kernel_size=c["kernel_size"], concat_input=c["concat_input"],
                         dropout_ratio=0.0, in_index=c["in_index"])
         _run_head(head, npz, "fcn", c)
+
+
+def test_losses_wiring_and_values(wiring):
+    """`losses` of the FCN / PSP heads run from the reference's own source with the reference's own
+    cross_entropy, weight_reduce_loss and accuracy: oracle.ops.seg_losses reproduces loss_seg and
+    acc_seg, and the recorded call order is resize(size = label size, bilinear, align_corners) ->
+    [sampler.sample(resized logits, label [N,1,H,W])] -> loss_decode(resized logits, label [N,H,W],
+    weight, ignore_index = 255) -> accuracy."""
+    from oracle import ops as O
+    meta, npz = wiring
+    for c in meta["losses"]:
+        t = c["tag"]
+        logits = torch.from_numpy(npz["losses_%s_logits" % t])
+        label = torch.from_numpy(npz["losses_%s_label" % t])
+        pw = torch.from_numpy(npz["losses_%s_pixel_weight" % t])
+        cw = torch.from_numpy(npz["losses_%s_class_weight" % t]) if c["class_weight"] else None
+        sampler = (lambda lg, lb: pw) if c["sampler"] else None
+        got = O.seg_losses(logits, label, c["loss_weight"], 255, c["align_corners"], sampler, cw)
+        assert close(got["loss_seg"], npz["losses_%s_loss_seg" % t], 1e-6), t
+        assert close(got["acc_seg"], npz["losses_%s_acc_seg" % t], 1e-6), t
+        names = [r[0] for r in c["trace"]]
+        assert names == ["resize"] + (["sampler.sample"] if c["sampler"] else []) + ["loss_decode"]
+        rs = c["trace"][0]
+        assert rs[2] == [list(label.shape[2:]), "bilinear", c["align_corners"]]
+        ld = c["trace"][-1]
+        assert ld[1] == [logits.shape[0], logits.shape[1]] + list(label.shape[2:])     # resized logits
+        assert ld[2] == [[label.shape[0]] + list(label.shape[2:]), c["sampler"], 255]  # squeezed label
+        assert c["keys"] == ["acc_seg", "loss_seg"] + (["resize_logit"] if c["head"] == "psp" else [])

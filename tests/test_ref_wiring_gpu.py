@@ -112,3 +112,26 @@ def test_fcn_head(hip_lib, wiring):
         _head_case("fcn", c, npz, dict(type="DynamicFCNHead", in_channels=c["in_channels"],
                                        in_index=c["in_index"], num_convs=c["num_convs"],
                                        kernel_size=c["kernel_size"], concat_input=c["concat_input"]))
+
+
+def test_losses_fused_resize_ce(hip_lib, wiring):
+    """The product's `losses` (fused resize + cross entropy + accuracy kernel, the full-resolution
+    logits never exist) against the values the reference's own `losses` code produced
+    (dynamic_fcn_head.py:137-159 / dynamic_psp_head.py:149-173 with its cross_entropy and accuracy)."""
+    from gaia_seg_amd.hip.runtime import Act
+    from gaia_seg_amd.models.losses import seg_loss_and_accuracy
+    meta, npz = wiring
+    for c in meta["losses"]:
+        t = c["tag"]
+        logits = torch.from_numpy(npz["losses_%s_logits" % t])
+        n, k, h, w = logits.shape
+        a = Act.empty(n, h, w, k, torch.device(DEV))
+        a.t.copy_(logits.permute(0, 2, 3, 1))
+        label = torch.from_numpy(npz["losses_%s_label" % t]).to(DEV)
+        pw = torch.from_numpy(npz["losses_%s_pixel_weight" % t]).to(DEV) if c["sampler"] else None
+        cw = torch.from_numpy(npz["losses_%s_class_weight" % t]).to(DEV) if c["class_weight"] else None
+        loss, acc = seg_loss_and_accuracy(a.as_nchw(), label, pw, cw, 255, c["align_corners"],
+                                          c["loss_weight"])
+        want_l, want_a = npz["losses_%s_loss_seg" % t].item(), npz["losses_%s_acc_seg" % t].item()
+        assert abs(float(loss) - want_l) < 2e-5 * max(1.0, abs(want_l)), t
+        assert abs(float(acc) - want_a) < 100.0 * 2.01 / label.numel(), t    # argmax ties: <= 2 pixels
