@@ -22,6 +22,8 @@ sizes / mode / align_corners, the top-down add order of the FPN, dropout -> conv
   DynamicFCNHead.forward                     gaiaseg/models/decode_heads/dynamic_fcn_head.py:128-135
   DynamicFCNHead.losses / DynamicPSPHead.losses   dynamic_fcn_head.py:137-159, dynamic_psp_head.py:149-173
      (with the reference's own cross_entropy / weight_reduce_loss / accuracy)
+  DynamicDistiller.encode_decode / slide_inference / whole_inference / inference / simple_test /
+     aug_test                                gaiaseg/models/segmentors/dynamic_distiller.py:252-262,416-540
 
 Fixture: for every case the state_dict of the stand-ins (keys = the reference's module names), the
 seeded inputs, the outputs, and the call trace [(child name, input shape, extra args)] incl. every
@@ -448,6 +450,74 @@ def case_losses(out, meta, gen):
     meta["losses"] = cases
 
 
+def standin_low_logits(img, w1x1):
+    """The decode head of the inference fixtures: 8x average pooling of the image, then a fixed 1x1
+    conv to the classes -- low-resolution logits [N, C, h/8, w/8] (ceil).  Shared with the tests."""
+    return F.conv2d(F.avg_pool2d(img, 8, ceil_mode=True), w1x1)
+
+
+def case_inference(out, meta, gen):
+    """encode_decode / slide_inference / whole_inference / inference / simple_test / aug_test of the
+    reference's segmentor (gaiaseg/models/segmentors/dynamic_distiller.py:252-262, 416-540) -- the
+    test-time epilogue -- run from its own source.  extract_feat is the identity and the decode head's
+    forward_test the stand-in above, so encode_decode's resize and everything behind it is the
+    reference's code."""
+    rel, cls = "gaiaseg/models/segmentors/dynamic_distiller.py", "DynamicDistiller"
+    trace = Trace()
+    ns = dict(torch=torch, F=F, resize=_resize_recorder(trace), all=all, list=list, len=len, range=range,
+              max=max, min=min, int=int)
+    fns = {n: _extract(rel, n, cls, ns) for n in ("encode_decode", "slide_inference", "whole_inference",
+                                                  "inference", "simple_test", "aug_test")}
+    ncls = 7
+    w1x1 = torch.randn(ncls, 3, 1, 1, generator=gen) * 2
+    out["inf_w1x1"] = w1x1.numpy()
+    cases = []
+
+    def segmentor(mode, align, crop=None, stride=None):
+        fk = types.SimpleNamespace(align_corners=align, num_classes=ncls, with_neck=False,
+                                   test_cfg=types.SimpleNamespace(mode=mode, crop_size=crop, stride=stride))
+        fk.extract_feat = lambda img: img
+        fk._decode_head_forward_test = lambda x, metas: standin_low_logits(x, w1x1)
+        for n, f in fns.items():
+            setattr(fk, n, types.MethodType(f, fk))
+        return fk
+
+    def meta_of(ori, flip=False, direction="horizontal"):
+        return dict(ori_shape=(ori[0], ori[1], 3), flip=flip, flip_direction=direction)
+    for tag, mode, align, hw, ori, flip, direction, crop, stride in [
+            ("whole", "whole", False, (64, 96), (64, 96), False, "horizontal", None, None),
+            ("whole_rescale_hflip", "whole", False, (64, 96), (50, 70), True, "horizontal", None, None),
+            ("whole_align_vflip", "whole", True, (40, 56), (40, 56), True, "vertical", None, None),
+            ("slide", "slide", False, (64, 96), (64, 96), False, "horizontal", (32, 48), (21, 32)),
+            ("slide_rescale", "slide", False, (72, 104), (90, 130), False, "horizontal", (40, 56), (24, 40))]:
+        fk = segmentor(mode, align, crop, stride)
+        img = torch.randn(2, 3, hw[0], hw[1], generator=gen)
+        metas = [meta_of(ori, flip, direction)] * 2
+        del trace[:]
+        prob = fk.inference(img, metas, True)
+        seg = fk.simple_test(img, metas, True)
+        out["inf_%s_img" % tag] = img.numpy()
+        if tag in ("whole_rescale_hflip", "slide"):     # (probabilities of two cases: fixture size)
+            out["inf_%s_prob" % tag] = prob.numpy()
+        out["inf_%s_seg" % tag] = np.stack(seg)
+        cases.append(dict(tag=tag, mode=mode, align_corners=align, ori_shape=list(ori), flip=flip,
+                          flip_direction=direction, crop_size=crop and list(crop),
+                          stride=stride and list(stride),
+                          resizes=[t for t in trace if t[0] == "resize"][:4]))
+    # aug_test: three views of one 60 x 84 original (scaled, flipped), averaged probabilities
+    fk = segmentor("whole", False)
+    views = [((60, 84), False, "horizontal"), ((48, 64), True, "horizontal"), ((72, 104), True, "vertical")]
+    imgs = [torch.randn(1, 3, v[0][0], v[0][1], generator=gen) for v in views]
+    metas = [[meta_of((60, 84), v[1], v[2])] for v in views]
+    seg = fk.aug_test(imgs, metas, True)
+    for i, im in enumerate(imgs):
+        out["inf_aug_img%d" % i] = im.numpy()
+    out["inf_aug_seg"] = np.stack(seg)
+    meta["inference"] = dict(num_classes=ncls, cases=cases,
+                             aug=dict(ori_shape=[60, 84], views=[dict(size=list(v[0]), flip=v[1],
+                                                                      flip_direction=v[2]) for v in views]))
+
+
 def main():
     torch.manual_seed(0)
     gen = torch.Generator().manual_seed(20240)
@@ -458,6 +528,7 @@ def main():
     case_uper(out, meta, gen)
     case_fcn(out, meta, gen)
     case_losses(out, meta, gen)
+    case_inference(out, meta, gen)
     np.savez_compressed(os.path.join(HERE, "ref_wiring.npz"), **out)
     with open(os.path.join(HERE, "ref_wiring.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -206,3 +206,56 @@ def test_losses_wiring_and_values(wiring):
         assert ld[1] == [logits.shape[0], logits.shape[1]] + list(label.shape[2:])     # resized logits
         assert ld[2] == [[label.shape[0]] + list(label.shape[2:]), c["sampler"], 255]  # squeezed label
         assert c["keys"] == ["acc_seg", "loss_seg"] + (["resize_logit"] if c["head"] == "psp" else [])
+
+
+def standin_low_logits(img, w1x1):
+    """the fixture's stand-in decode head (tests/golden/make_ref_wiring_fixtures.py)"""
+    import torch.nn.functional as F
+    return F.conv2d(F.avg_pool2d(img, 8, ceil_mode=True), w1x1)
+
+
+class _FakeSegmentor:
+    """what oracle/inference.py needs of a model: encode_decode + decode_head.align_corners"""
+
+    def __init__(self, w1x1, align):
+        import types
+        self.w, self.decode_head = w1x1, types.SimpleNamespace(align_corners=align)
+
+    def encode_decode(self, img):
+        from oracle import ops as O
+        return O.resize(standin_low_logits(img, self.w), size=img.shape[2:], mode="bilinear",
+                        align_corners=self.decode_head.align_corners)
+
+
+def _labels_agree(got, want, prob=None):
+    got, want = torch.as_tensor(got), torch.as_tensor(want)
+    assert got.shape == want.shape
+    return int((got != want).sum())
+
+
+def test_inference_epilogue_against_the_reference_methods(wiring):
+    """encode_decode -> slide / whole inference -> rescale -> softmax -> flip back -> argmax, and
+    aug_test's mean over views, as the reference's own methods computed them
+    (dynamic_distiller.py:252-262, 416-540): oracle/inference.py reproduces the probabilities (1e-6)
+    and every label."""
+    from oracle import inference as OI
+    meta, npz = wiring
+    inf = meta["inference"]
+    w = torch.from_numpy(npz["inf_w1x1"])
+    for c in inf["cases"]:
+        model = _FakeSegmentor(w, c["align_corners"])
+        img = torch.from_numpy(npz["inf_%s_img" % c["tag"]])
+        m = dict(ori_shape=tuple(c["ori_shape"]) + (3,), flip=c["flip"], flip_direction=c["flip_direction"])
+        cfg = dict(mode=c["mode"], crop_size=c["crop_size"], stride=c["stride"])
+        prob = OI.inference(model, img, m, cfg, rescale=True)
+        key = "inf_%s_prob" % c["tag"]
+        if key in npz.files:
+            assert close(prob, npz[key], 1e-6), c["tag"]
+        assert _labels_agree(prob.argmax(1), npz["inf_%s_seg" % c["tag"]]) == 0, c["tag"]
+    a = inf["aug"]
+    model = _FakeSegmentor(w, False)
+    imgs = [torch.from_numpy(npz["inf_aug_img%d" % i]) for i in range(len(a["views"]))]
+    metas = [dict(ori_shape=tuple(a["ori_shape"]) + (3,), flip=v["flip"], flip_direction=v["flip_direction"])
+             for v in a["views"]]
+    seg = OI.aug_test(model, imgs, metas, dict(mode="whole"), rescale=True)
+    assert _labels_agree(seg, npz["inf_aug_seg"]) == 0

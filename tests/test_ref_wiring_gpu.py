@@ -135,3 +135,56 @@ def test_losses_fused_resize_ce(hip_lib, wiring):
         want_l, want_a = npz["losses_%s_loss_seg" % t].item(), npz["losses_%s_acc_seg" % t].item()
         assert abs(float(loss) - want_l) < 2e-5 * max(1.0, abs(want_l)), t
         assert abs(float(acc) - want_a) < 100.0 * 2.01 / label.numel(), t    # argmax ties: <= 2 pixels
+
+
+def test_inference_epilogue_fused_kernel(hip_lib, wiring):
+    """The product segmentor's test-time methods (inference / simple_test / aug_test: ONE fused
+    epilogue kernel per view, csrc/inference.hip, all windows batched) against what the reference's own
+    encode_decode / slide_inference / whole_inference / inference / simple_test / aug_test computed
+    (dynamic_distiller.py:252-262, 416-540).  extract_feat is patched to the identity and the decode
+    head's forward_test to the fixture's stand-in, exactly as the generator did on the reference side."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_ref_wiring import standin_low_logits
+    from util_models import fcn_head, model_cfg
+    from gaia_seg_amd.core.config import ConfigDict
+    from gaia_seg_amd.models import build_segmentor
+    meta, npz = wiring
+    inf = meta["inference"]
+    w = torch.from_numpy(npz["inf_w1x1"]).to(DEV)
+    model = build_segmentor(model_cfg(fcn_head(), aux=False)).to(DEV).eval()
+    model.extract_feat = lambda img: img
+    model._decode_head_forward_test = lambda x, metas: standin_low_logits(x, w)
+    model.decode_head.num_classes = model.num_classes = inf["num_classes"]
+
+    def check_labels(got, want, prob_ref=None):
+        got = torch.as_tensor(np.stack(got))
+        want = torch.as_tensor(want)
+        differ = got != want
+        n = int(differ.sum())
+        if n and prob_ref is not None:     # a differing pixel must be an argmax tie within rounding
+            top2 = torch.as_tensor(prob_ref).topk(2, dim=1).values
+            assert float((top2[:, 0] - top2[:, 1])[differ].max()) < 1e-5
+        assert n <= 2, n
+
+    for c in inf["cases"]:
+        model.align_corners = model.decode_head.align_corners = c["align_corners"]
+        model.test_cfg = ConfigDict(dict(mode=c["mode"], crop_size=c["crop_size"], stride=c["stride"]))
+        img = torch.from_numpy(npz["inf_%s_img" % c["tag"]]).to(DEV)
+        metas = [dict(ori_shape=tuple(c["ori_shape"]) + (3,), flip=c["flip"],
+                      flip_direction=c["flip_direction"])] * img.shape[0]
+        key = "inf_%s_prob" % c["tag"]
+        prob_ref = npz[key] if key in npz.files else None
+        with torch.no_grad():
+            if prob_ref is not None:
+                prob = model.inference(img, metas, True)
+                assert close(prob.cpu(), prob_ref, 2e-5), c["tag"]
+            check_labels(model.simple_test(img, metas, True), npz["inf_%s_seg" % c["tag"]], prob_ref)
+    a = inf["aug"]
+    model.align_corners = model.decode_head.align_corners = False
+    model.test_cfg = ConfigDict(dict(mode="whole"))
+    imgs = [torch.from_numpy(npz["inf_aug_img%d" % i]).to(DEV) for i in range(len(a["views"]))]
+    metas = [[dict(ori_shape=tuple(a["ori_shape"]) + (3,), flip=v["flip"], flip_direction=v["flip_direction"])]
+             for v in a["views"]]
+    with torch.no_grad():
+        check_labels(model.aug_test(imgs, metas, True), npz["inf_aug_seg"])
