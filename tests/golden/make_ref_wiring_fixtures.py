@@ -518,6 +518,46 @@ def case_inference(out, meta, gen):
                                                                       flip_direction=v[2]) for v in views]))
 
 
+def case_forward_train(out, meta, gen):
+    """EncoderDecoder.forward_train and its two head wrappers as restated in the reference tree
+    ("dynamic_encoder_decoder-distill-backup (1).py":85-143; the class the in-tree
+    DynamicEncoderDecoder inherits them from is mmseg's, absent): which head gets which arguments, the
+    'decode.' / 'aux.' / 'aux_<i>.' key prefixes (mmseg.core.add_prefix [3P]: {prefix.key: value})."""
+    rel, cls = "gaiaseg/models/segmentors/dynamic_encoder_decoder-distill-backup (1).py", "DynamicEncoderDecoder"
+
+    def add_prefix(inputs, prefix):
+        return {"%s.%s" % (prefix, k): v for k, v in inputs.items()}
+    ns = dict(dict=dict, nn=nn, isinstance=isinstance, enumerate=enumerate, add_prefix=add_prefix)
+    fns = {n: _extract(rel, n, cls, ns) for n in ("forward_train", "_decode_head_forward_train",
+                                                  "_auxiliary_head_forward_train")}
+    cases = []
+    for tag, aux in [("single_aux", "one"), ("aux_list", "list"), ("no_aux", None)]:
+        calls = []
+
+        class Head(nn.Module):
+            def __init__(self, name, base):
+                super().__init__()
+                self.name, self.base = name, base
+
+            def forward_train(self, x, img_metas, gt, train_cfg):
+                calls.append([self.name, [list(t.shape) for t in x], len(img_metas), list(gt.shape),
+                              train_cfg])
+                return {"loss_seg": torch.tensor(self.base + 0.25), "acc_seg": torch.tensor(self.base * 10)}
+        fk = types.SimpleNamespace(train_cfg="TRAIN_CFG", decode_head=Head("decode_head", 1.0))
+        fk.extract_feat = lambda img: (img[:, :1] * 2, img[:, 1:] * 3)
+        if aux == "one":
+            fk.auxiliary_head = Head("auxiliary_head", 2.0)
+        elif aux == "list":
+            fk.auxiliary_head = nn.ModuleList([Head("auxiliary_head.0", 2.0), Head("auxiliary_head.1", 3.0)])
+        fk.with_auxiliary_head = aux is not None
+        for n, f in fns.items():
+            setattr(fk, n, types.MethodType(f, fk))
+        losses = fk.forward_train(torch.zeros(2, 3, 8, 8), [{}, {}], torch.zeros(2, 1, 8, 8, dtype=torch.long))
+        cases.append(dict(tag=tag, aux=aux, calls=calls, losses={k: float(v) for k, v in losses.items()},
+                          order=list(losses.keys())))
+    meta["forward_train"] = cases
+
+
 def main():
     torch.manual_seed(0)
     gen = torch.Generator().manual_seed(20240)
@@ -529,6 +569,7 @@ def main():
     case_fcn(out, meta, gen)
     case_losses(out, meta, gen)
     case_inference(out, meta, gen)
+    case_forward_train(out, meta, gen)
     np.savez_compressed(os.path.join(HERE, "ref_wiring.npz"), **out)
     with open(os.path.join(HERE, "ref_wiring.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -259,3 +259,41 @@ def test_inference_epilogue_against_the_reference_methods(wiring):
              for v in a["views"]]
     seg = OI.aug_test(model, imgs, metas, dict(mode="whole"), rescale=True)
     assert _labels_agree(seg, npz["inf_aug_seg"]) == 0
+
+
+def test_segmentor_forward_train_prefixes_and_call_order(wiring):
+    """EncoderDecoder.forward_train as the reference tree restates it ("dynamic_encoder_decoder-
+    distill-backup (1).py":85-143): decode head first, then the auxiliary head(s); every head gets
+    (features, img_metas, gt, train_cfg); keys 'decode.*', 'aux.*' or 'aux_<i>.*' in that order.  The
+    product segmentor's forward_train (host logic, no GPU needed) reproduces calls, keys, values."""
+    import torch.nn as nn
+    from gaia_seg_amd.models.segmentors import DynamicEncoderDecoder
+    meta, _ = wiring
+    for c in meta["forward_train"]:
+        calls = []
+
+        class Head(nn.Module):
+            def __init__(self, name, base):
+                super().__init__()
+                self.name, self.base = name, base
+
+            def forward_train(self, x, img_metas, gt, train_cfg):
+                calls.append([self.name, [list(t.shape) for t in x], len(img_metas), list(gt.shape), train_cfg])
+                return {"loss_seg": torch.tensor(self.base + 0.25), "acc_seg": torch.tensor(self.base * 10)}
+        seg = DynamicEncoderDecoder.__new__(DynamicEncoderDecoder)
+        nn.Module.__init__(seg)
+        seg.train_cfg = "TRAIN_CFG"
+        seg.decode_head = Head("decode_head", 1.0)
+        if c["aux"] == "one":
+            seg.auxiliary_head = Head("auxiliary_head", 2.0)
+        elif c["aux"] == "list":
+            seg.auxiliary_head = nn.ModuleList([Head("auxiliary_head.0", 2.0), Head("auxiliary_head.1", 3.0)])
+        seg.extract_feat = lambda img: (img[:, :1] * 2, img[:, 1:] * 3)
+        losses = seg.forward_train(torch.zeros(2, 3, 8, 8), [{}, {}], torch.zeros(2, 1, 8, 8, dtype=torch.long))
+        assert calls == c["calls"], c["tag"]
+        assert list(losses.keys()) == c["order"], c["tag"]
+        assert {k: float(v) for k, v in losses.items()} == c["losses"], c["tag"]
+        # total loss = the sum over the entries whose key contains 'loss' (mmseg _parse_losses, [3P])
+        loss, log_vars = seg._parse_losses(losses)
+        assert abs(float(loss) - sum(v for k, v in c["losses"].items() if "loss" in k)) < 1e-6
+        assert set(log_vars) == set(c["losses"]) | {"loss"}
