@@ -455,9 +455,12 @@ def main():
     seg0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
     import ctypes
     L.gs_debug_conv_launch_flops(None, 1)
+    L.gs_debug_k3_flops(None, 1)
     passes = [timed_pass(False)]                     # <- `value`: nothing but the training steps
     kl = (ctypes.c_double * 15)()
     L.gs_debug_conv_launch_flops(kl, 1)              # which MFMA path carried the first pass's FLOPs
+    k3kl = (ctypes.c_double * 5)()
+    L.gs_debug_k3_flops(k3kl, 1)
     seg_new = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0) - seg0
     bytes_per_step = (reducer.bytes_reduced - bytes0) / max(args.steps, 1)
     collectives_per_step = reducer.collectives / max(args.steps, 1) if world > 1 else 0.0
@@ -530,9 +533,10 @@ def main():
                           "inside every timed step" if args.data == "pipeline" else
                           "resident synthetic fp32 batches"),
                 "device_mallocs_in_timed_steps": int(seg_new),
-                "contraction": "fp32 MFMA (forward, weight gradient); data gradient: six bf16 MFMAs "
-                               "over an exact three-way bf16 split of both operands, fp32 "
-                               "accumulation (error vs fp64 as the fp32 MFMA; GS_X3=0 turns it off)",
+                "contraction": "fp32 MFMA (weight gradient, most forwards); stride-1 data gradients and "
+                               "the 3x3 forwards where it measured ahead: six bf16 MFMAs over an exact "
+                               "three-way bf16 split of both operands, fp32 accumulation (error vs fp64 "
+                               "as the fp32 MFMA; GS_X3=0 / GS_X3_FWD=0 turn it off)",
                 "step_graphs": dict(runner.graph_stats, built_at_startup=graphs_built,
                                     what="HIP-graph replay of recurring subnets' whole training "
                                          "step (same kernels as the eager step); counts cover "
@@ -568,6 +572,8 @@ def main():
         if k3 is not None:
             launches, ms, flops, el_i = k3
             achieved = flops / (ms * 1e-3) / 1e12
+            k3_x3 = k3kl[3] / (sum(k3kl) or 1.0)
+            k3_bound = 1.0 / ((1.0 - k3_x3) / FP32_MFMA_PEAK_TFLOPS + k3_x3 / X3_LDS_BOUND_TFLOPS)
             traffic, traffic_src = k3_traffic()
             out["roofline"] = {
                 "kernel": "igemm_rows_*_kernel<..., KS=3, ROLE=1> (+ its split-K reduce where used): "
@@ -583,8 +589,13 @@ def main():
                 "algorithmic_check": "host replay of the %d draws: %d launches, %.3f GF per launch"
                                      % (args.steps, k3_alg["launches"],
                                         k3_alg["flops"] / max(k3_alg["launches"], 1) / 1e9),
-                "k_loop": "fp32 MFMA (v_mfma_f32_16x16x4_f32); forward FLOPs on the bf16x3 loop: %.1f %%"
-                          % (100.0 * kl[3] / fwd_tot),
+                "flop_share_by_k_loop": {"fp32_mfma": round(1.0 - k3_x3, 4), "bf16x3": round(k3_x3, 4)},
+                "blended_bound": round(k3_bound, 1),
+                "frac_of_blended_bound": round(achieved / k3_bound, 4),
+                "bound_note": "`frac` = fp32-equivalent FLOPs / the 157.3 TF fp32 MFMA peak; the K3 launches "
+                              "dispatched to the bf16x3 loop (stage 1, split-K stages) are bounded by LDS "
+                              "bandwidth at %.0f fp32-equivalent TF instead: blended bound above"
+                              % X3_LDS_BOUND_TFLOPS,
                 "measured_in": "a separate instrumented pass over the same %d draws (%.3f ms/step; "
                                "`value` is from the un-instrumented pass)"
                                % (args.steps, 1e3 * el_i / args.steps),

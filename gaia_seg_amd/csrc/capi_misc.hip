@@ -35,7 +35,9 @@ namespace gs {
 thread_local gs_debug_launch g_last_launch = {-1, 0, 0, 0, 0, 0, 0, 0};
 long long g_launch_counts[3][GS_KLOOP_COUNT][3] = {};
 double g_launch_flops[3][GS_KLOOP_COUNT] = {};
+double g_k3_flops[GS_KLOOP_COUNT] = {};
 int g_stream_mode = -1;
+int g_x3_fwd = -1;
 }
 extern "C" int gs_debug_last_conv_launch(gs_debug_launch* out) {
   if (!out) return GS_E_NULL;
@@ -50,6 +52,20 @@ extern "C" int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset) {
         if (counts) counts[(o * GS_KLOOP_COUNT + k) * 3 + m] = __atomic_load_n(&gs::g_launch_counts[o][k][m], __ATOMIC_RELAXED);
         if (reset) __atomic_store_n(&gs::g_launch_counts[o][k][m], 0LL, __ATOMIC_RELAXED);
       }
+  return GS_OK;
+}
+
+extern "C" int gs_debug_k3_flops(double* flops, int32_t reset) {
+  for (int k = 0; k < GS_KLOOP_COUNT; ++k) {
+    if (flops) flops[k] = gs::g_k3_flops[k];
+    if (reset) gs::g_k3_flops[k] = 0.0;
+  }
+  return GS_OK;
+}
+
+extern "C" int gs_debug_set_x3_fwd(int32_t mode) {
+  if (mode < -1 || mode > 2) return GS_E_BADARG;
+  gs::g_x3_fwd = mode;           // -1: back to the environment's GS_X3_FWD (default 1)
   return GS_OK;
 }
 

@@ -786,6 +786,25 @@ __device__ __forceinline__ void x3_split(const f32x4 lo4, const f32x4 hi4, u32x4
   p2 = x3_pack(__builtin_bit_cast(u32x4, r2l), __builtin_bit_cast(u32x4, r2h));
 }
 
+// Interleaved form for the forward: the 16-byte chunk holds [lo0, hi0, lo1, hi1, lo2, hi2, lo3, hi3]
+// (element j of the first 16-channel step next to element j of the second), so that a thread which
+// holds ONE k row of the [k][n] weights per step owns an adjacent bf16 pair per output column.
+__device__ __forceinline__ u32x4 x3_pack_il(const u32x4 a, const u32x4 b) {
+  return u32x4{(a[0] >> 16) | (b[0] & 0xFFFF0000u), (a[1] >> 16) | (b[1] & 0xFFFF0000u),
+               (a[2] >> 16) | (b[2] & 0xFFFF0000u), (a[3] >> 16) | (b[3] & 0xFFFF0000u)};
+}
+__device__ __forceinline__ void x3_split_il(const f32x4 lo4, const f32x4 hi4, u32x4& p0, u32x4& p1,
+                                            u32x4& p2) {
+  const u32x4 mask{0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u};
+  const u32x4 hl = __builtin_bit_cast(u32x4, lo4) & mask, hh = __builtin_bit_cast(u32x4, hi4) & mask;
+  const f32x4 r1l = lo4 - __builtin_bit_cast(f32x4, hl), r1h = hi4 - __builtin_bit_cast(f32x4, hh);
+  const u32x4 ml = __builtin_bit_cast(u32x4, r1l) & mask, mh = __builtin_bit_cast(u32x4, r1h) & mask;
+  const f32x4 r2l = r1l - __builtin_bit_cast(f32x4, ml), r2h = r1h - __builtin_bit_cast(f32x4, mh);
+  p0 = x3_pack_il(hl, hh);
+  p1 = x3_pack_il(ml, mh);
+  p2 = x3_pack_il(__builtin_bit_cast(u32x4, r2l), __builtin_bit_cast(u32x4, r2h));
+}
+
 // one LDS stage (two barriers per step, three workgroups per CU by registers) or two (one barrier,
 // two workgroups per CU by LDS)
 constexpr int kX3Stages = 1;
@@ -799,7 +818,10 @@ struct X3Tile {
   static constexpr int LDS_FLOATS = kX3Stages * STAGE / 4;
 };
 
-template <int BM, int BN, int AS, class LA, class LB>
+// BFWD (forward): B arrives as one k ROW of the [k][n] weights per thread and step -- four columns
+// (b_row .. b_row + 3) of k row b_kq (0..15) -- and both operands use the interleaved chunk order;
+// the pair (step 1 value, step 2 value) of a column is one 32-bit LDS store per piece.
+template <int BM, int BN, int AS, bool BFWD = false, class LA, class LB>
 __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
                                           f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN],
                                           int wave, int lane, int t, int b_row, int b_kq,
@@ -822,12 +844,26 @@ __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
   };
   auto sstore = [&](int set, unsigned char* st) __attribute__((always_inline)) {
     u32x4 p0, p1, p2;
-    x3_split(a0[set][0], a1[set][0], p0, p1, p2);
+    if constexpr (BFWD) x3_split_il(a0[set][0], a1[set][0], p0, p1, p2);
+    else x3_split(a0[set][0], a1[set][0], p0, p1, p2);
     unsigned char* pa = st + row * X::ROWB + kq * 16;
     *reinterpret_cast<u32x4*>(pa) = p0;
     *reinterpret_cast<u32x4*>(pa + X::PA) = p1;
     *reinterpret_cast<u32x4*>(pa + 2 * X::PA) = p2;
-    if (b_on) {
+    if constexpr (BFWD) {
+      if (b_on) {
+        // element e of the thread's row pair = column b_row + e: (step 1, step 2) as one dword at
+        // chunk b_kq >> 2, pair slot b_kq & 3 of that column's row
+        x3_split_il(b0[set][0], b1[set][0], p0, p1, p2);
+        unsigned char* pb = st + 3 * X::PA + b_row * X::ROWB + (b_kq >> 2) * 16 + (b_kq & 3) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          *reinterpret_cast<unsigned*>(pb + e * X::ROWB) = p0[e];
+          *reinterpret_cast<unsigned*>(pb + e * X::ROWB + X::PB) = p1[e];
+          *reinterpret_cast<unsigned*>(pb + e * X::ROWB + 2 * X::PB) = p2[e];
+        }
+      }
+    } else if (b_on) {
       x3_split(b0[set][0], b1[set][0], p0, p1, p2);
       unsigned char* pb = st + 3 * X::PA + b_row * X::ROWB + b_kq * 16;
       *reinterpret_cast<u32x4*>(pb) = p0;
@@ -1145,22 +1181,21 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
         ra[AS + 3][0] = __builtin_bit_cast(float, okbits);
       }
     };
-    // bf16x3 forward: the stage needs, per column n, four CONSECUTIVE k of the [k][n] weights in one
-    // thread (they become one 16-byte bf16 chunk).  Thread (n = t & 63, chunk = wave) fetches them
-    // as four dword loads; across a wave each of them is one contiguous 256-byte row segment.
-    const int x3_col = n0 + (t & 63);
-    const bool x3_bok = (t & 63) < BN && x3_col < p.n_lim;
-    const int x3_boff = 4 * ((4 * (t >> 6)) * p.d_row + x3_col);
+    // bf16x3 forward: thread (k row kr = lane & 15 of the 16-channel step, column quad
+    // nq = (lane >> 4) + 4 * wave) fetches ONE 16-byte quad of the [k][n] weights per step, like the
+    // fp32 loop (a wave reads 16 rows x 64 contiguous bytes).  The k rows run fastest over the lanes so
+    // that the 32-bit pair stores of x3_k_loop<BFWD> walk consecutive LDS banks.  (r02 fetched four
+    // consecutive k of one column as four dword loads per step: 4x the vector-memory instructions,
+    // level with the fp32 loop.)
+    const int x3_kr = lane & 15, x3_nq = (lane >> 4) + 4 * wave;
+    const int x3_col = n0 + 4 * x3_nq;
+    const bool x3_bok = 4 * x3_nq < BN && x3_col < p.n_lim;
+    const int x3_boff = 4 * (x3_kr * p.d_row + x3_col);
     auto load_b = [&](f32x4 (&rb)[T::BV]) __attribute__((always_inline)) {
       const bool kvalid = k_left > 0;
       if constexpr (X3 && !BTRANS) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const unsigned off = (x3_bok && kvalid) ? (unsigned)(x3_boff + 4 * e * p.d_row + bbase) : kOOB;
-          v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dense, off, 0, 0));
-        }
-        rb[0] = v;
+        const unsigned off = (x3_bok && kvalid) ? (unsigned)(x3_boff + bbase) : kOOB;
+        rb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dense, off, 0, 0));
       } else
 #pragma unroll
       for (int r = 0; r < T::BV; ++r) {
@@ -1218,8 +1253,8 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     };
     GS_STAMP(st_l0)
     if constexpr (X3)
-      x3_k_loop<BM, BN, AX>(nk, lds, acc, wave, lane, t, BTRANS ? (t >> 2) : (t & 63),
-                            BTRANS ? (t & 3) : (t >> 6), load_a, load_b);
+      x3_k_loop<BM, BN, AX, !BTRANS>(nk, lds, acc, wave, lane, t, BTRANS ? (t >> 2) : 4 * x3_nq,
+                                     BTRANS ? (t & 3) : x3_kr, load_a, load_b);
     else if constexpr (PAIR)
       pipelined_k_loop_pairs<BM, BN, AX>(nk, lds, acc, wave, lane, load_a, load_b, store_a, store_b);
     else
@@ -1698,6 +1733,7 @@ constexpr size_t kMaxSlabBytes = 96u << 20;
 extern thread_local gs_debug_launch g_last_launch;
 extern long long g_launch_counts[3][GS_KLOOP_COUNT][3];
 extern double g_launch_flops[3][GS_KLOOP_COUNT];   // algorithmic 2*M*N*K per (op, K loop); single-writer per stream thread
+extern double g_k3_flops[GS_KLOOP_COUNT];          // the same for the role-1 (bottleneck conv2) forward launches
 static inline void note_launch(int op, int kloop, const Plan& pl, bool aff, int bw_mode,
                                double flops = 0.0) {
   g_launch_flops[op][kloop] += flops;
@@ -1858,6 +1894,14 @@ static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
 // most three workgroups per CU anyway (its four LDS stages allow no more); big grids and short K
 // ranges keep the two-stage loop, whose smaller footprint lets five workgroups per CU overlap their
 // fill / drain (r01 A/B: s2..s4 3x3 and the head convs +3..7 %, s1 3x3 -3 % if paired).
+// forward on the bf16x3 loop: 0 = never, 1 = where it measured ahead of the fp32 loops (default), 2 =
+// wherever the loop's gate admits it (tests, sweeps); GS_X3_FWD sets the initial value,
+// gs_debug_set_x3_fwd changes it at run time
+extern int g_x3_fwd;   // capi_misc.hip (-1 = not yet read from the environment)
+static inline int x3_fwd_mode() {
+  if (g_x3_fwd < 0) g_x3_fwd = env_int("GS_X3_FWD", 1);
+  return g_x3_fwd;
+}
 static inline bool pair_loop_ok(const Plan& pl) {
   return pl.nk_per_split >= pair_min_ksteps() &&
          (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * num_cu();
@@ -1868,13 +1912,21 @@ static inline bool x3_grid_ok(const Plan& pl, int min_ksteps_) {
          (long)pl.tiles_m * pl.tiles_n * pl.splits >= 2L * num_cu();
 }
 template <bool BTRANS>
-static inline int rows_fast_kloop(const Plan& pl, bool in_affine) {
+static inline int rows_fast_kloop(const Plan& pl, bool in_affine, int ks = 3) {
   if constexpr (BTRANS) {
     static const int x3_min = env_int("GS_X3", 4);
     if (x3_grid_ok(pl, x3_min) && (pl.bn == 64 || pl.bn == 48)) return GS_KLOOP_BF16X3;
   } else {
-    static const int x3_fwd = env_int("GS_X3_FWD", 0);
-    if (!in_affine && x3_grid_ok(pl, x3_fwd) && pl.bn == 64) return GS_KLOOP_BF16X3;
+    // Forward (r03: the [k][n] weights staged one k row per thread and step, x3_k_loop<BFWD>).
+    // Per shape against the fp32 loops, kernels alone (profiles/r03_fwd_x3_per_shape.md): 3x3 at
+    // stage 1 +9 % (one K step per barrier there), the split-K 3x3s of stages 3-4 +3..5 %, the
+    // unsplit 3x3 of stage 2 -4 % (the two-steps-per-barrier fp32 loop wins), 1x1s -10..+8 %
+    // without a pattern.  Production: 3x3 only, and not where the paired fp32 loop runs unsplit.
+    const int mode = x3_fwd_mode();
+    if (mode > 0 && !in_affine && x3_grid_ok(pl, 4) && (pl.bn == 64 || pl.bn == 48)) {
+      if (mode >= 2) return GS_KLOOP_BF16X3;
+      if (ks == 3 && !(pair_loop_ok(pl) && pl.splits == 1)) return GS_KLOOP_BF16X3;
+    }
   }
   return pair_loop_ok(pl) ? GS_KLOOP_FP32_PAIRS : GS_KLOOP_FP32;
 }
@@ -1889,18 +1941,21 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
     a.tile_order = force >= 0 ? force : (b_bytes > a_bytes ? 1 : 0);
   }
   const dim3 grid(pl.tiles_m * pl.tiles_n * pl.splits), block(NT);
-  const int kloop = rows_fast_kloop<BTRANS>(pl, a.a_coeffs != nullptr);
+  const int kloop = rows_fast_kloop<BTRANS>(pl, a.a_coeffs != nullptr, KS);
   const bool pair = kloop == GS_KLOOP_FP32_PAIRS;
   note_launch(BTRANS ? GS_OP_DGRAD : GS_OP_FORWARD, kloop, pl, a.a_coeffs != nullptr, a.bw_mode,
               2.0 * a.M * (double)a.Nn * a.Ktot);
+  if (ROLE == 1 && !BTRANS) g_k3_flops[kloop] += 2.0 * a.M * (double)a.Nn * a.Ktot;
   if (kloop == GS_KLOOP_BF16X3) {
     if constexpr (BTRANS) {
       if (pl.bn == 64)
         hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, true, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
       else
         hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 48, true, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
-    } else {
+    } else if (pl.bn == 64) {
       hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, false, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
+    } else {
+      hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 48, false, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
     }
     return;
   }

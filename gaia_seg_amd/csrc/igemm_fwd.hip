@@ -189,7 +189,7 @@ extern "C" int gs_debug_query_conv_launch(const gs_conv_desc* d, int32_t op, gs_
     pl = plan_fwd(d);
     const size_t src_b = (size_t)d->N * d->x_sn * sizeof(float);
     if (vec && fast_rows_ok(d->Ci, ks, src_b, w_bytes) && !no_fast) {
-      kloop = rows_fast_kloop<false>(pl, aff);
+      kloop = rows_fast_kloop<false>(pl, aff, ks);
       const StreamPlan sp = stream_fwd_plan(d, true, nullptr, nullptr);
       if (sp.ok) {
         kloop = GS_KLOOP_STREAM;

@@ -152,6 +152,8 @@ PROTOTYPES = {
                                    POINTER(_i32)]),
     "gs_debug_last_conv_launch": (_i32, [POINTER(DebugLaunch)]),
     "gs_debug_conv_launch_counts": (_i32, [POINTER(_i64), _i32]),
+    "gs_debug_k3_flops": (_i32, [POINTER(_f64), _i32]),
+    "gs_debug_set_x3_fwd": (_i32, [_i32]),
     "gs_debug_num_cu": (_i32, []),
     "gs_debug_set_stream_mode": (_i32, [_i32]),
     "gs_debug_conv_launch_flops": (_i32, [POINTER(_f64), _i32]),

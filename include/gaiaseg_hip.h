@@ -528,6 +528,11 @@ int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset);
  * which MFMA path, so that its roofline fractions name the right bound.  Not thread-safe (one
  * launching thread at a time, like the training step). */
 int gs_debug_conv_launch_flops(double* flops, int32_t reset);
+/* Forward convolutions on the bf16x3 K loop: 0 = never (fp32 MFMA loops), 1 = the shapes where it
+ * measured ahead (default: 3x3, not where the two-steps-per-barrier fp32 loop runs unsplit), 2 = every
+ * launch the loop's gate admits (the operator tests), -1 = back to the GS_X3_FWD environment value.
+ * Process-global. */
+int gs_debug_set_x3_fwd(int32_t mode);
 /* Compute units the planners assume: hipDeviceProp::multiProcessorCount of the current device, read
  * once at first use (256 on an MI355X; 256 is also assumed when no device is present). */
 int gs_debug_num_cu(void);
@@ -536,6 +541,9 @@ int gs_debug_num_cu(void);
  * tests cover all of its code paths this way), -1 = back to the GS_STREAM environment value.
  * Process-global, not thread-safe. */
 int gs_debug_set_stream_mode(int32_t mode);
+/* The same for the forward launches with role GS_CONV_ROLE_BOTTLENECK3X3 only: flops[kloop], 5 entries
+ * (which bound bench.py's headline `roofline` is priced against). */
+int gs_debug_k3_flops(double* flops, int32_t reset);
 /* What gs_conv2d_forward / _dgrad / _wgrad (op = GS_OP_*) WOULD launch for this descriptor: host
  * arithmetic only, no GPU needed (honours gs_debug_force_plan and the GS_X3 switches).  For a strided
  * dgrad it describes the parity class (0, 0). */
