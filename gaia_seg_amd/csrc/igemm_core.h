@@ -808,6 +808,15 @@ __device__ __forceinline__ void x3_split_il(const f32x4 lo4, const f32x4 hi4, u3
 // one LDS stage (two barriers per step, three workgroups per CU by registers) or two (one barrier,
 // two workgroups per CU by LDS)
 constexpr int kX3Stages = 1;
+// Product terms a_i * b_j kept per element pair: 6 = all with i + j <= 2 (drops a1 b2 + a2 b1, each
+// 2^-24 of |a||b| -- the size of one fp32 rounding -- and a2 b2); 8 = those two as well, leaving only
+// a2 b2 (2^-32): the contraction is then exact to BELOW fp32 rounding and the only error left is the
+// fp32 accumulation inside the MFMA.  The loop is bound by operand traffic, not by the MFMA pipe
+// (33 % busy at six terms), so the two extra MFMAs are nearly free.
+#ifndef GS_X3_TERMS
+#define GS_X3_TERMS 8
+#endif
+constexpr int kX3Terms = GS_X3_TERMS;
 constexpr int kX3Sets = 2;     // register sets = how many steps the global loads run ahead
 
 template <int BN>
@@ -892,6 +901,10 @@ __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i2 = q >> 1, j2 = q & 1;
+        if constexpr (kX3Terms == 8) {   // the 2^-24-level cross terms (see kX3Terms)
+          acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][2], qb[j2][1], acc[0][q], 0, 0, 0);
+          acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][1], qb[j2][2], acc[0][q], 0, 0, 0);
+        }
         acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][2], qb[j2][0], acc[0][q], 0, 0, 0);
         acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][1], qb[j2][1], acc[0][q], 0, 0, 0);
         acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i2][0], qb[j2][2], acc[0][q], 0, 0, 0);
@@ -912,6 +925,10 @@ __device__ __forceinline__ void x3_k_loop(int nk16, float* ldsf,
       for (int p = 0; p < 3; ++p)
         fb[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
             cb + 3 * X::PA + p * X::PB + brow[j] * X::ROWB + fk * 16));
+      if constexpr (kX3Terms == 8) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[1], acc[0][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[2], acc[0][j], 0, 0, 0);
+      }
       acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0], acc[0][j], 0, 0, 0);
       acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1], acc[0][j], 0, 0, 0);
       acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2], acc[0][j], 0, 0, 0);
