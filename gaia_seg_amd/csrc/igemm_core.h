@@ -810,11 +810,13 @@ __device__ __forceinline__ void x3_split_il(const f32x4 lo4, const f32x4 hi4, u3
 constexpr int kX3Stages = 1;
 // Product terms a_i * b_j kept per element pair: 6 = all with i + j <= 2 (drops a1 b2 + a2 b1, each
 // 2^-24 of |a||b| -- the size of one fp32 rounding -- and a2 b2); 8 = those two as well, leaving only
-// a2 b2 (2^-32): the contraction is then exact to BELOW fp32 rounding and the only error left is the
-// fp32 accumulation inside the MFMA.  The loop is bound by operand traffic, not by the MFMA pipe
-// (33 % busy at six terms), so the two extra MFMAs are nearly free.
+// a2 b2 (2^-32).  Measured (r03): 8 terms cost 9 % (stage-1 3x3 dgrad 47.6 -> 52.4 us) and do NOT
+// lower the loop's noise -- with the forward on x3 the conditioned-gradient error ratios of the
+// full-size parity tests were 1.53 / 3 outliers with 6 terms and 1.59 / 1.61 with 8 -- so the extra
+// noise over the fp32 MFMA's exact fmaf chain is the bf16 MFMA's internal 32-term accumulation, not
+// the dropped cross terms.  6 it is.
 #ifndef GS_X3_TERMS
-#define GS_X3_TERMS 8
+#define GS_X3_TERMS 6
 #endif
 constexpr int kX3Terms = GS_X3_TERMS;
 constexpr int kX3Sets = 2;     // register sets = how many steps the global loads run ahead
