@@ -1917,8 +1917,8 @@ static void launch_rows(const Plan& pl, const IgemmArgs& a, hipStream_t st) {
 // wherever the loop's gate admits it (tests, sweeps); GS_X3_FWD sets the initial value,
 // gs_debug_set_x3_fwd changes it at run time.
 // Why off: it is faster (K3 +2 % on the sampled mix, +9 % at stage 1) and passes every operator test
-// at 3e-5, but the bf16x3 contraction drops the 2^-24-level cross terms (a1 b2 + a2 b1) and is
-// ~1.3-1.5x noisier than the exact fmaf chain of the fp32 MFMA: with the forward on it as well, the
+// at 3e-5, but the bf16x3 contraction is ~1.3-1.5x noisier than the exact fmaf chain of the fp32
+// MFMA (the bf16 MFMA's internal accumulation: see kX3Terms): with the forward on it as well, the
 // median error ratio of the ill-conditioned parameter gradients against the fp32 oracle rose from
 // 1.15 to 1.53 on config 4 (bound 1.5, tests/parity.py) and three parameters of config 3 left the
 // 3x bound.  Parity is the first gate; the data gradient alone (r02 default) stays inside it.
