@@ -2,7 +2,7 @@
 
   config 1  FCN + the [64,128,256,512]/[2,2,2,2] bottleneck subnet ("R18-like": the reference has no
             BasicBlock, dynamic_resnet.py:132-133), 512x512, bs 2, forward + backward
-  config 2  FCN + R50..R101 supernet, 1024x512, bs 2: anchors MIN, R50, MAX and a seeded random draw
+  config 2  FCN + R50..R101 supernet, 1024x512, bs 2: anchors MIN, MAX and a seeded random draw (R50: config 5)
   config 3  PSP + aux FCN (the reference's pspnet_ar50to101v2_gsync model), 1024x512, bs 2, one rank
   config 4  UPer + R101 anchor, 769x769, bs 4 (every tile edge is ragged at 193/97/49/25)
   OS8       the reference's v1c supernet (deep stem, dilations (1,1,2,4)) + PSP + aux, R50 anchor,
@@ -135,7 +135,10 @@ def _train_case(name, arch, n, h, w, **head_updates):
 
 
 # ---- config 2 -------------------------------------------------------------------------------
-@pytest.mark.parametrize("anchor", ["MIN", "R50", "MAX"])
+# (the R50 anchor of this supernet is compared -- losses, BN statistics, every gradient -- by
+# test_config5_ohem_train_step_2048x1024 at the same pixel count, and its losses once more by
+# bench.py's first-step gate; the GPU suite has a time budget, so it is not run a third time here)
+@pytest.mark.parametrize("anchor", ["MIN", "MAX"])
 def test_config2_fcn_supernet_1024x512_bs2(hip_lib, anchor):
     _train_case("fcn_ar50to101v2.py", ANCHORS[anchor], 2, 512, 1024)
 
