@@ -568,6 +568,41 @@ __device__ __forceinline__ void rows_epilogue(
 }
 
 
+// Progress priority (experiment, GS_PRIO > 0): a wave lowers its issue priority as it advances through
+// its K range, so that the co-resident workgroups of a CU -- which the arbiter otherwise serves
+// oldest-first, finishing them one after the other and leaving the CU under-occupied for the last
+// third of a single-round launch -- advance together.  `done` of `total` loop units.
+#ifndef GS_PRIO
+#define GS_PRIO 0
+#endif
+__device__ __forceinline__ void progress_prio(int done, int total) {
+#if GS_PRIO == 1
+  const int q = total >> 2;
+  if (done >= 3 * q) __builtin_amdgcn_s_setprio(0);
+  else if (done >= 2 * q) __builtin_amdgcn_s_setprio(1);
+  else if (done >= q) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+#elif GS_PRIO == 2   // finer towards the end: 50 %, 75 %, 90 %
+  if (10 * done >= 9 * total) __builtin_amdgcn_s_setprio(0);
+  else if (4 * done >= 3 * total) __builtin_amdgcn_s_setprio(1);
+  else if (2 * done >= total) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+#elif GS_PRIO == 3   // inverted (control): priority rises with progress
+  const int q = total >> 2;
+  if (done >= 3 * q) __builtin_amdgcn_s_setprio(3);
+  else if (done >= 2 * q) __builtin_amdgcn_s_setprio(2);
+  else if (done >= q) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#else
+  (void)done; (void)total;
+#endif
+}
+__device__ __forceinline__ void progress_prio_end() {
+#if GS_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // Software-pipelined K loop shared by the fast row and wgrad kernels.
 // One wave can run only ONE MFMA ahead of its instruction stream, so everything else a K step
@@ -644,6 +679,7 @@ __device__ __forceinline__ void pipelined_k_loop(int nk, float* lds,
   read_b(buf0, 0, fb[0]);
   int ib = 0;
   for (; ib + 6 <= nk; ib += 6) {   // unconditional body (see pipelined_k_loop_pairs)
+    progress_prio(ib, nk);
     phase(ra0, rb0, ra1, rb1, buf0, buf1);
     phase(ra1, rb1, ra2, rb2, buf1, buf0);
     phase(ra2, rb2, ra0, rb0, buf0, buf1);
@@ -656,6 +692,7 @@ __device__ __forceinline__ void pipelined_k_loop(int nk, float* lds,
   if (ib + 2 < nk) phase(ra2, rb2, ra0, rb0, buf0, buf1);
   if (ib + 3 < nk) phase(ra0, rb0, ra1, rb1, buf1, buf0);
   if (ib + 4 < nk) phase(ra1, rb1, ra2, rb2, buf0, buf1);
+  progress_prio_end();
 }
 
 
@@ -741,12 +778,14 @@ __device__ __forceinline__ void pipelined_k_loop_pairs(
   // drain, r01 ISA; the odd pair is peeled off instead)
   int pp = 0;
   for (; pp + 1 < npairs; pp += 2) {
+    progress_prio(pp, npairs);
     // pair in A, next pair (held in sets 2,3) -> B, refill sets 0,1
     phase(ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3, A0, A1, B0, B1);
     // pair in B, next pair (sets 0,1) -> A, refill sets 2,3
     phase(ra2, rb2, ra3, rb3, ra0, rb0, ra1, rb1, B0, B1, A0, A1);
   }
   if (pp < npairs) phase(ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3, A0, A1, B0, B1);
+  progress_prio_end();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1324,7 +1363,11 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     if (lane == 0) {
       unsigned long long* o = reinterpret_cast<unsigned long long*>(keep) + ((long)blockIdx.x * 4 + wave) * 8;
       o[0] = st_k0; o[1] = st_l1 - st_l0; o[2] = st_entry; o[3] = r_end;
-      o[4] = d_load; o[5] = d_mfma; o[6] = d_store; o[7] = d_bar;
+      o[4] = d_load; o[5] = d_mfma; o[6] = d_store;
+      // HW_REG_HW_ID (4) and HW_REG_XCC_ID (20), all 32 bits: which CU / SIMD ran this wave
+      o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+             ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+      (void)d_bar;
     }
   } else {
     rows_epilogue<BM, BN, (X3 && BN == 64)>(p, lds, acc, m0, n0, t, wave, lane, split);
