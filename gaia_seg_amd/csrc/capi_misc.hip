@@ -1,7 +1,7 @@
 // Library identification and error text of the gaiaseg_hip C-ABI.
 #include "common.h"
 
-extern "C" int gs_abi_version(void) { return 6; }
+extern "C" int gs_abi_version(void) { return 7; }
 
 extern "C" const char* gs_target_arch(void) { return "gfx950"; }
 

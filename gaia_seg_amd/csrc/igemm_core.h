@@ -71,7 +71,8 @@ struct IgemmArgs {
   // dgrad only: the output dX is the gradient of z = relu(bn(y) [+ residual]) of the PRODUCER layer.
   // bw_mode != 0 folds that BatchNorm's backward reduction into this epilogue: the tile (after the
   // optional accumulate) is masked with the ReLU mask (mode 1: (y - mean) * scale + beta > 0,
-  // mode 2: bw_act > 0), the masked gradient g is what gets stored, and per-tile sums
+  // mode 2: bw_act > 0, mode 3: the same mask as bytes, one per channel quad, written by the
+  // producer's bn_apply), the masked gradient g is what gets stored, and per-tile sums
   // {sum g, sum g * xhat} go to bw_part ([2][Nn/4][tiles_m] float4, quad-major) for
   // sum_partials_kernel — the separate bn_bwd_partial pass over dz and y disappears.
   const float* bw_y;       // the producer BN's input, pixel stride bw_ldy
@@ -79,6 +80,8 @@ struct IgemmArgs {
   const float* bw_coeffs;  // [scale | beta | mean | invstd][Nn]
   float* bw_part;
   int bw_ldy, bw_ldact, bw_mode;
+  const unsigned char* bw_mask;   // mode 3: [pixels][bw_ldmask] bytes, bit e of byte q <=> channel 4q+e
+  int bw_ldmask;
 };
 
 constexpr int kAffMaxC = 640;   // widest gathered operand of the supernet (stage-4 planes)
@@ -477,11 +480,17 @@ __device__ __forceinline__ void rows_epilogue(
           float* o = p.out + pix * p.ld_out + col;
           if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
           const f32x4 yv = *reinterpret_cast<const f32x4*>(p.bw_y + pix * p.bw_ldy + col);
-          f32x4 key;
-          if (p.bw_mode == 2) key = *reinterpret_cast<const f32x4*>(p.bw_act + pix * p.bw_ldact + col);
-          else key = (yv - mean) * scale + beta;          // the expression of bn_apply / masked_grad
+          if (p.bw_mode == 3) {
+            const unsigned bits = p.bw_mask[pix * p.bw_ldmask + (col >> 2)];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = key[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] = ((bits >> e) & 1u) ? v[e] : 0.f;
+          } else {
+            f32x4 key;
+            if (p.bw_mode == 2) key = *reinterpret_cast<const f32x4*>(p.bw_act + pix * p.bw_ldact + col);
+            else key = (yv - mean) * scale + beta;          // the expression of bn_apply / masked_grad
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = key[e] > 0.f ? v[e] : 0.f;
+          }
           *reinterpret_cast<f32x4*>(o) = v;
           s1 += v;
           s2 += v * ((yv - mean) * invstd);
@@ -1801,7 +1810,9 @@ static inline void note_launch(int op, int kloop, const Plan& pl, bool aff, int 
   g_launch_flops[op][kloop] += flops;
   g_last_launch = gs_debug_launch{op, kloop, pl.bm, pl.bn, pl.splits, pl.nk_per_split, aff ? 1 : 0,
                                   bw_mode};
-  __atomic_fetch_add(&g_launch_counts[op][kloop][bw_mode < 0 || bw_mode > 2 ? 0 : bw_mode], 1LL, __ATOMIC_RELAXED);
+  // (mode 3 = mode 2's mask read from bytes: counted with mode 2, the record keeps the 3)
+  const int bwi = bw_mode == 3 ? 2 : (bw_mode < 0 || bw_mode > 2 ? 0 : bw_mode);
+  __atomic_fetch_add(&g_launch_counts[op][kloop][bwi], 1LL, __ATOMIC_RELAXED);
 }
 
 // Tuning knobs (read once): GS_WG_TARGET = workgroups a launch should reach before we stop

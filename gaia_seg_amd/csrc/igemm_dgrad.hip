@@ -120,6 +120,18 @@ size_t dgrad_bnbwd_part_bytes(const gs_conv_desc* d) {
   return (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
 }
 
+// the fused BatchNorm-backward epilogue can take this request: mode 1 (mask recomputed), 2 (mask from
+// the activation) or 3 (mask bytes), operands present and 16-byte aligned where they are read as quads
+static inline bool bnbwd_fuse_ok(const gs_bn_bwd_fuse* bw, const gs_conv_desc* d, const void* workspace) {
+  if (!bw || !bw->y || !bw->coeffs || !bw->sums || !workspace || !aligned16(workspace)) return false;
+  if (!aligned16(bw->y) || !aligned16(bw->coeffs) || (bw->ldy & 3) != 0 || bw->ldy < d->Ci) return false;
+  if (bw->mode == 1) return true;
+  if (bw->mode == 2)
+    return bw->act && aligned16(bw->act) && (bw->ldact & 3) == 0 && bw->ldact >= d->Ci;
+  if (bw->mode == 3) return bw->mask && bw->ldmask >= d->Ci / 4 && bw->reserved2 == 0;
+  return false;
+}
+
 int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, float* dx,
                       int accumulate, void* workspace, size_t workspace_bytes, void* stream,
                       const gs_bn_bwd_fuse* bw, int* fused) {
@@ -172,13 +184,11 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
   const StreamPlan sp = (fast && ks == 1 && d->stride == 1) ? stream_plan(M, d->Ci, d->Co, true)
                                                             : StreamPlan{0, 0, 0, 0, 0};
   if (sp.ok) {
-    if (bw && !no_bnb && bw->y && bw->coeffs && bw->sums &&
-        (bw->mode == 1 || (bw->mode == 2 && bw->act)) && workspace && aligned16(workspace) &&
-        aligned16(bw->y) && aligned16(bw->coeffs) && (bw->ldy & 3) == 0 && bw->ldy >= d->Ci &&
-        (bw->mode == 1 || (aligned16(bw->act) && (bw->ldact & 3) == 0 && bw->ldact >= d->Ci)) &&
+    if (bnbwd_fuse_ok(bw, d, workspace) && !no_bnb &&
         (size_t)2 * d->Ci * sp.row_groups * sizeof(float) <= workspace_bytes) {
       a.bw_y = bw->y; a.bw_ldy = bw->ldy; a.bw_act = bw->act; a.bw_ldact = bw->ldact;
       a.bw_coeffs = bw->coeffs; a.bw_mode = bw->mode;
+      a.bw_mask = bw->mask; a.bw_ldmask = bw->ldmask;
       a.bw_part = static_cast<float*>(workspace);
       bnb = true;
     }
@@ -191,15 +201,13 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
     }
     return rc;
   }
-  if (bw && !no_bnb && d->stride == 1 && fast && bw->y && bw->coeffs && bw->sums &&
-      (bw->mode == 1 || (bw->mode == 2 && bw->act)) && workspace && aligned16(workspace) &&
-      aligned16(bw->y) && aligned16(bw->coeffs) && (bw->ldy & 3) == 0 && bw->ldy >= d->Ci &&
-      (bw->mode == 1 || (aligned16(bw->act) && (bw->ldact & 3) == 0 && bw->ldact >= d->Ci))) {
+  if (!no_bnb && d->stride == 1 && fast && bnbwd_fuse_ok(bw, d, workspace)) {
     if (pl.splits == 1) {
       const size_t part_b = (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
       if (part_b <= workspace_bytes) {
         a.bw_y = bw->y; a.bw_ldy = bw->ldy; a.bw_act = bw->act; a.bw_ldact = bw->ldact;
         a.bw_coeffs = bw->coeffs; a.bw_mode = bw->mode;
+        a.bw_mask = bw->mask; a.bw_ldmask = bw->ldmask;
         a.bw_part = static_cast<float*>(workspace);
         bnb = true;
       }

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kStreamThreads) void conv1x1_stream_kernel(const Ig
       }
       // issue every load of the group first, then combine and store
       f32x4 prev[4], yv[4], av[4];
-      unsigned off[4];
+      unsigned off[4], mbits[4];
       bool ok[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -270,6 +270,8 @@ __global__ __launch_bounds__(kStreamThreads) void conv1x1_stream_kernel(const Ig
             if (p.bw_mode == 2) {
               const unsigned oa = ok[r] ? 4u * ((unsigned)m * (unsigned)p.bw_ldact + (unsigned)col) : kOOB;
               av[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bwa, oa, 0, 0));
+            } else if (p.bw_mode == 3) {
+              mbits[r] = ok[r] ? (unsigned)p.bw_mask[(long)m * p.bw_ldmask + (col >> 2)] : 0u;
             }
           }
         }
@@ -280,9 +282,14 @@ __global__ __launch_bounds__(kStreamThreads) void conv1x1_stream_kernel(const Ig
         if constexpr (BTRANS) {
           if (p.accumulate) v += prev[r];
           if (want_bnb) {
-            const f32x4 key = p.bw_mode == 2 ? av[r] : (yv[r] - mean) * scale + beta;   // as bn_apply / masked_grad
+            if (p.bw_mode == 3) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (ok[r] && key[e] > 0.f) ? v[e] : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = ((mbits[r] >> e) & 1u) ? v[e] : 0.f;
+            } else {
+              const f32x4 key = p.bw_mode == 2 ? av[r] : (yv[r] - mean) * scale + beta;   // as bn_apply / masked_grad
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (ok[r] && key[e] > 0.f) ? v[e] : 0.f;
+            }
             s1[g] += v;
             s2[g] += v * ((yv[r] - mean) * invstd);
           }

@@ -241,11 +241,14 @@ __global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(const float* __rest
 }
 
 // y = act((x - mean) * scale + beta (+ residual))
-template <bool RES, bool RELU>
+// MASKOUT (with RELU): also mask[r][cq] = one byte per channel quad, bit e set <=> y[r][4cq+e] > 0 --
+// what the fused BatchNorm-backward epilogue of the consumer's data gradient needs of y (mode 3 of
+// gs_bn_bwd_fuse): 1/16 of the bytes of reading y again.
+template <bool RES, bool RELU, bool MASKOUT = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, long rows, int C, int ldx,
                                                        const float* __restrict__ coeffs,
                                                        const float* res, int ld_res, float* y,
-                                                       int ldy) {  // x / res / y may alias
+                                                       int ldy, unsigned char* __restrict__ mask) {  // x / res / y may alias
   const int C4 = C >> 2;
   const ColMap m = col_map(C4);
   if (!m.active) return;
@@ -258,6 +261,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, long rows
     v = (v - mean) * scale + beta;
     if (RES) v += *reinterpret_cast<const f32x4*>(res + r * ld_res + m.cq * 4);
     if (RELU) {
+      if (MASKOUT)
+        mask[r * C4 + m.cq] = (unsigned char)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) |
+                                              (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0));
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
       v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
@@ -509,7 +515,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void splitk_reduce_bnbwd_kernel(
     const float* __restrict__ slab, int splits, long rows, int C, float* dx, int ld_dx, int accumulate,
     const float* __restrict__ yprev, int ldy, const float* __restrict__ act, int ldact,
-    const float* __restrict__ coeffs, long rows_per_block, float* __restrict__ part) {
+    const float* __restrict__ coeffs, long rows_per_block, float* __restrict__ part,
+    const unsigned char* __restrict__ mask, int ldmask) {
   __shared__ f32x4 sh[512];
   const int C4 = C >> 2;
   const ColMap m = col_map(C4);
@@ -531,7 +538,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_bnbwd_kernel(
       const f32x4 yv = *reinterpret_cast<const f32x4*>(yprev + r * ldy + m.cq * 4);
       f32x4 av{0.f, 0.f, 0.f, 0.f};
       if (MODE == 2) av = *reinterpret_cast<const f32x4*>(act + r * ldact + m.cq * 4);
-      v = masked_grad<MODE>(v, yv, av, mean, scale, beta);
+      if (MODE == 3) {
+        const unsigned bits = mask[r * ldmask + m.cq];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((bits >> e) & 1u) ? v[e] : 0.f;
+      } else {
+        v = masked_grad<MODE>(v, yv, av, mean, scale, beta);
+      }
       *reinterpret_cast<f32x4*>(o) = v;
       s1 += v;
       s2 += v * ((yv - mean) * invstd);
@@ -660,14 +673,18 @@ int bn_reduce_bnbwd(const float* slab, int splits, long rows, int C, float* dx, 
                     hipStream_t st) {
   const RedGeom g = red_geom(rows, C);
   if ((size_t)g.gx * 2 * C * sizeof(float) > part_bytes) return GS_E_WORKSPACE;
-  if (bw->mode == 2)
+  if (bw->mode == 3)
+    hipLaunchKernelGGL(splitk_reduce_bnbwd_kernel<3>, dim3(g.gx, g.gy), dim3(256), 0, st, slab, splits,
+                       rows, C, dx, ld_dx, accumulate, bw->y, bw->ldy, (const float*)nullptr, 0,
+                       bw->coeffs, g.rows_per_block, part, bw->mask, bw->ldmask);
+  else if (bw->mode == 2)
     hipLaunchKernelGGL(splitk_reduce_bnbwd_kernel<2>, dim3(g.gx, g.gy), dim3(256), 0, st, slab, splits,
                        rows, C, dx, ld_dx, accumulate, bw->y, bw->ldy, bw->act, bw->ldact, bw->coeffs,
-                       g.rows_per_block, part);
+                       g.rows_per_block, part, (const unsigned char*)nullptr, 0);
   else
     hipLaunchKernelGGL(splitk_reduce_bnbwd_kernel<1>, dim3(g.gx, g.gy), dim3(256), 0, st, slab, splits,
                        rows, C, dx, ld_dx, accumulate, bw->y, bw->ldy, bw->act, bw->ldact, bw->coeffs,
-                       g.rows_per_block, part);
+                       g.rows_per_block, part, (const unsigned char*)nullptr, 0);
   launch_sum_partials(part, g.gx, 2 * C, bw->sums, nullptr, 0, st);
   return launch_status();
 }
@@ -755,9 +772,9 @@ extern "C" int gs_bn_eval_coeffs(const float* running_mean, const float* running
   return launch_status();
 }
 
-extern "C" int gs_bn_apply(const float* x, int64_t rows, int32_t C, int32_t ldx,
-                           const float* coeffs, const float* residual, int32_t ld_res,
-                           int32_t relu, float* y, int32_t ldy, void* stream) {
+static int bn_apply_impl(const float* x, int64_t rows, int32_t C, int32_t ldx, const float* coeffs,
+                         const float* residual, int32_t ld_res, int32_t relu, float* y, int32_t ldy,
+                         unsigned char* mask, void* stream) {
   int rc = check_rows(x, rows, C, ldx);
   if (rc) return rc;
   rc = check_rows(y, rows, C, ldy);
@@ -769,11 +786,34 @@ extern "C" int gs_bn_apply(const float* x, int64_t rows, int32_t C, int32_t ldx,
   hipStream_t st = as_stream(stream);
 #define GS_APPLY(R, A)                                                                          \
   hipLaunchKernelGGL((bn_apply_kernel<R, A>), grid, dim3(256), 0, st, x, (long)rows, C, ldx,    \
-                     coeffs, residual, ld_res, y, ldy)
+                     coeffs, residual, ld_res, y, ldy, (unsigned char*)nullptr)
+  if (mask) {
+    if (!relu) return GS_E_BADARG;
+    if (residual)
+      hipLaunchKernelGGL((bn_apply_kernel<true, true, true>), grid, dim3(256), 0, st, x, (long)rows, C,
+                         ldx, coeffs, residual, ld_res, y, ldy, mask);
+    else
+      hipLaunchKernelGGL((bn_apply_kernel<false, true, true>), grid, dim3(256), 0, st, x, (long)rows, C,
+                         ldx, coeffs, residual, ld_res, y, ldy, mask);
+    return launch_status();
+  }
   if (residual) { if (relu) GS_APPLY(true, true); else GS_APPLY(true, false); }
   else { if (relu) GS_APPLY(false, true); else GS_APPLY(false, false); }
 #undef GS_APPLY
   return launch_status();
+}
+
+extern "C" int gs_bn_apply(const float* x, int64_t rows, int32_t C, int32_t ldx,
+                           const float* coeffs, const float* residual, int32_t ld_res,
+                           int32_t relu, float* y, int32_t ldy, void* stream) {
+  return bn_apply_impl(x, rows, C, ldx, coeffs, residual, ld_res, relu, y, ldy, nullptr, stream);
+}
+
+extern "C" int gs_bn_apply_mask(const float* x, int64_t rows, int32_t C, int32_t ldx,
+                                const float* coeffs, const float* residual, int32_t ld_res, float* y,
+                                int32_t ldy, uint8_t* mask, void* stream) {
+  if (!mask) return GS_E_NULL;
+  return bn_apply_impl(x, rows, C, ldx, coeffs, residual, ld_res, 1, y, ldy, mask, stream);
 }
 
 extern "C" int gs_bn_bwd_reduce(const float* dy, int32_t ld_dy, const float* x, int32_t ldx,

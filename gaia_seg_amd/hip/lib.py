@@ -16,7 +16,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgaiaseg_hip.so")
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HipLibraryError(RuntimeError):
@@ -38,14 +38,14 @@ class BnArgs(Structure):
     _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p),
                 ("running_var", c_void_p), ("eps", c_float), ("momentum", c_float),
                 ("use_batch_stats", c_int32), ("update_running", c_int32), ("relu", c_int32),
-                ("reserved", c_int32)]
+                ("reserved", c_int32), ("relu_mask", c_void_p)]
 
 
 class BnBwdFuse(Structure):
     """Mirror of ``gs_bn_bwd_fuse``."""
     _fields_ = [("y", c_void_p), ("act", c_void_p), ("coeffs", c_void_p), ("sums", c_void_p),
                 ("fused", POINTER(c_int32)), ("ldy", c_int32), ("ldact", c_int32), ("mode", c_int32),
-                ("reserved", c_int32)]
+                ("reserved", c_int32), ("mask", c_void_p), ("ldmask", c_int32), ("reserved2", c_int32)]
 
 
 class DebugLaunch(Structure):
@@ -108,6 +108,7 @@ PROTOTYPES = {
                                     _P]),
     "gs_bn_eval_coeffs": (_i32, [_P, _P, _i32, _P, _P, _f32, _P, _P]),
     "gs_bn_apply": (_i32, [_P, _i64, _i32, _i32, _P, _P, _i32, _i32, _P, _i32, _P]),
+    "gs_bn_apply_mask": (_i32, [_P, _i64, _i32, _i32, _P, _P, _i32, _P, _i32, _P, _P]),
     "gs_bn_bwd_workspace_bytes": (_sz, [_i64, _i32]),
     "gs_bn_bwd_reduce": (_i32, [_P, _i32, _P, _i32, _P, _i32, _i64, _i32, _P, _i32, _P, _i32, _P,
                                 _P, _sz, _P]),

@@ -545,7 +545,9 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
 
 
 BNBWD_FUSE = os.environ.get("GS_NO_BNBWD_FUSE") is None
+RELU_MASK_BYTES = os.environ.get("GS_RELU_MASK_BYTES", "1") != "0"   # gs_bn_bwd_fuse mode 3
 BNBWD_FUSED_COUNT = 0   # diagnostics: how many BN-backward reductions ran inside a dgrad epilogue
+BNBWD_FUSED_MASK_COUNT = 0   # ... of which took their ReLU mask from the mask bytes (mode 3)
 
 
 class _ConvBnPlan:
@@ -643,6 +645,14 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
     elif out is None:
         out = Act.empty(pl.n, pl.ho, pl.wo, co, dev)
     _bn_pointers(args, bn)
+    # A block output relu(bn(y) + identity) whose consumer may fold this BatchNorm's backward
+    # reduction into its data-gradient epilogue: the apply pass also writes the ReLU mask as one byte
+    # per channel quad, so that epilogue reads rows * C / 4 bytes instead of the activation again
+    relu_mask = None
+    if (RELU_MASK_BYTES and relu and residual is not None and not defer and use_batch and BNBWD_FUSE
+            and tape.enabled and out.parent is None):
+        relu_mask = torch.empty((rows, C // 4), dtype=torch.uint8, device=dev)
+    args.relu_mask = relu_mask.data_ptr() if relu_mask is not None else None
     # [scale | beta | mean | invstd][C] + a 2C slot for this BatchNorm's backward sums (filled by
     # this layer's backward, or by its consumer's dgrad epilogue): one small allocation per layer
     coeffs = torch.empty(6 * C, dtype=torch.float32, device=dev)
@@ -667,7 +677,9 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
         # live until Python's cyclic GC happens to run, and the caching allocator would answer with
         # ~15 hipMalloc calls per step (measured: reserved memory 7.7 -> 25 GB over 60 steps)
         # Likewise a deferred output IS its BN input y: stored as None, the consumer substitutes x.
-        out.bnb = (None if out is y else y, coeffs, 2 if residual is not None else 1)
+        # (mode 3: the mask bytes written above stand in for the activation of mode 2)
+        out.bnb = (None if out is y else y, coeffs,
+                   3 if relu_mask is not None else (2 if residual is not None else 1), relu_mask)
     x_bnb = x.bnb if (owns_input_grad and BNBWD_FUSE and x.requires_grad) else None
     if not tape.enabled:
         return out
@@ -696,7 +708,7 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
             dx_ptr = x.g.data_ptr()
         fuse, fused_flag = None, None
         if x_bnb is not None and dx_ptr is not None and x.parent is None:
-            py, pcoeffs, pmode = x_bnb
+            py, pcoeffs, pmode, pmask = x_bnb
             if py is None:
                 py = x
             pact = x if pmode == 2 else None
@@ -708,6 +720,8 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
             fuse.coeffs, fuse.sums = pc, pc + 16 * (pcoeffs.numel() // 6)   # the producer's sums slot
             fuse.fused = ctypes.pointer(fused_flag)
             fuse.mode, fuse.reserved = pmode, 0
+            fuse.mask, fuse.ldmask, fuse.reserved2 = (
+                (pmask.data_ptr(), pmask.shape[1], 0) if pmode == 3 else (None, 0, 0))
         ws_b = _ws.get(need, dev)
         queued = SIDE_WGRAD and gw is not None
         d.in_affine = in_affine.data_ptr() if in_affine is not None else None
@@ -722,8 +736,10 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
             ctypes.byref(fuse) if fuse is not None else None, 1 if sums_ready else 0),
             "gs_conv_bn_backward")
         if fuse is not None and fused_flag.value:
-            global BNBWD_FUSED_COUNT
+            global BNBWD_FUSED_COUNT, BNBWD_FUSED_MASK_COUNT
             BNBWD_FUSED_COUNT += 1
+            if fuse.mode == 3:
+                BNBWD_FUSED_MASK_COUNT += 1
             x.bnb_sums = True        # x.g now holds the MASKED gradient of the producer's ReLU
         if wgrad_bn:
             _notify(bn.weight)

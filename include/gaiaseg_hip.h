@@ -154,6 +154,11 @@ int gs_bn_eval_coeffs(const float* running_mean, const float* running_var, int32
 int gs_bn_apply(const float* x, int64_t rows, int32_t C, int32_t ldx, const float* coeffs,
                 const float* residual, int32_t ld_res, int32_t relu, float* y, int32_t ldy,
                 void* stream);
+/* gs_bn_apply with ReLU that also writes the mask bytes mask[rows][C/4] (bit e of byte q set <=>
+ * y[r][4q+e] > 0), see gs_bn_args::relu_mask. */
+int gs_bn_apply_mask(const float* x, int64_t rows, int32_t C, int32_t ldx, const float* coeffs,
+                     const float* residual, int32_t ld_res, float* y, int32_t ldy, uint8_t* mask,
+                     void* stream);
 
 /* Backward.  mask_mode: 0 = none; 1 = ReLU directly after this BN (mask recomputed from
  * (x-mean)*scale+beta > 0); 2 = mask from a saved post-activation tensor `act` (> 0), used for the
@@ -198,6 +203,10 @@ typedef struct gs_bn_args {
   int32_t update_running;    /* 1: update running_mean / running_var (training mode)            */
   int32_t relu;              /* ReLU after the BN (+ residual)                                  */
   int32_t reserved;          /* must be 0                                                       */
+  uint8_t* relu_mask;        /* forward, relu != 0, z != NULL: if not NULL the apply pass also
+                                writes the ReLU mask [rows][Co/4], one byte per channel quad
+                                (bit e set <=> z[.., 4q+e] > 0) -- 1/16 of z, for the consumer's
+                                fused BatchNorm-backward epilogue (gs_bn_bwd_fuse mode 3)          */
 } gs_bn_args;
 /* max(gs_conv2d_workspace_bytes, gs_bn_stats_workspace_bytes) for this conv's output */
 size_t gs_conv_bn_workspace_bytes(const gs_conv_desc* d);
@@ -231,8 +240,12 @@ typedef struct gs_bn_bwd_fuse {
   float* sums;           /* out: [2*Ci] = {sum g, sum g * xhat}                                  */
   int32_t* fused;        /* out (host): 1 if the fused epilogue ran                             */
   int32_t ldy, ldact;
-  int32_t mode;          /* 1: mask = bn_prev(y) > 0 ; 2: mask = act > 0                        */
+  int32_t mode;          /* 1: mask = bn_prev(y) > 0 ; 2: mask = act > 0 ; 3: mask bits (below)  */
   int32_t reserved;
+  const uint8_t* mask;   /* mode 3: gs_bn_args::relu_mask of bn_prev's forward [rows][ldmask]:
+                            the same mask as mode 2 without reading the activation again         */
+  int32_t ldmask;        /* bytes per pixel row, >= Ci / 4                                       */
+  int32_t reserved2;     /* must be 0                                                            */
 } gs_bn_bwd_fuse;
 int gs_conv_bn_backward(const gs_conv_desc* d, const float* x, const float* w, const float* y,
                         const float* z, int32_t ldz, const float* coeffs, const gs_bn_args* bn,

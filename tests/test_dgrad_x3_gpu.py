@@ -182,8 +182,11 @@ def test_bn_backward_epilogue_on_the_bf16x3_loop(hip_lib, monkeypatch, stream_al
 
     layer = layer.to(DEV).train()
     results = {}
-    for fuse in (True, False):
-        monkeypatch.setattr(ops, "BNBWD_FUSE", fuse)
+    # (True: fused, bn3's ReLU mask as bytes -- mode 3; "act": fused, mask from the activation -- mode 2)
+    for fuse in (True, "act", False):
+        monkeypatch.setattr(ops, "BNBWD_FUSE", bool(fuse))
+        monkeypatch.setattr(ops, "RELU_MASK_BYTES", fuse is True)
+        ops.BNBWD_FUSED_MASK_COUNT = 0
         for p in layer.parameters():
             p.grad = None
         for m in layer.modules():
@@ -219,8 +222,13 @@ def test_bn_backward_epilogue_on_the_bf16x3_loop(hip_lib, monkeypatch, stream_al
             assert stm == ([2, 3, 2] if fuse else [7, 0, 0]), list(counts)
         else:
             assert stm == ([0, 0, 2] if fuse else [2, 0, 0]), list(counts)
+        assert ops.BNBWD_FUSED_MASK_COUNT == (2 if fuse is True else 0)
         results[fuse] = (z.detach().clone(), xg.grad.clone(),
                          {k: p.grad.clone() for k, p in layer.named_parameters()})
+    assert torch.equal(results[True][0], results["act"][0])
+    assert torch.equal(results[True][1], results["act"][1])      # mask bytes == mask from the activation
+    for k in results[True][2]:
+        assert torch.equal(results[True][2][k], results["act"][2][k]), k
     assert torch.equal(results[True][0], results[False][0])
     assert rel_err(results[True][1], results[False][1]) < 2e-5
     for k in results[True][2]:

@@ -176,6 +176,34 @@ def test_bn_near_constant_two_samples(hip_lib):
     assert rel_err(y, ref) < 1e-3
 
 
+@pytest.mark.parametrize("rows,C,ld,res", [(1000, 64, 64, True), (333, 1028, 1032, True), (77, 8, 8, False)])
+def test_bn_apply_writes_the_relu_mask_bytes(hip_lib, rows, C, ld, res):
+    """gs_bn_apply_mask (gs_bn_args::relu_mask): the same z as gs_bn_apply, plus one byte per channel
+    quad with bit e set <=> z[r][4q+e] > 0 -- the ReLU mask of relu(bn3(y) + identity)
+    (gaiaseg/models/utils/dynamic_res_layer.py:113-123) that gs_bn_bwd_fuse mode 3 consumes."""
+    torch.manual_seed(rows)
+    x = torch.randn(rows, ld, device=DEV)
+    r = torch.randn(rows, ld, device=DEV) if res else None
+    coeffs = torch.cat([torch.rand(C) + 0.5, torch.randn(C) * 0.3, torch.randn(C) * 0.2, torch.ones(C)]).to(DEV)
+    z0 = torch.full((rows, ld), 7.0, device=DEV)
+    z1 = torch.full((rows, ld), 7.0, device=DEV)
+    mask = torch.full((rows, C // 4), 255, dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    rp, rl = (r.data_ptr(), ld) if res else (None, 0)
+    assert hip_lib.gs_bn_apply(x.data_ptr(), rows, C, ld, coeffs.data_ptr(), rp, rl, 1, z0.data_ptr(), ld, st) == 0
+    assert hip_lib.gs_bn_apply_mask(x.data_ptr(), rows, C, ld, coeffs.data_ptr(), rp, rl, z1.data_ptr(), ld,
+                                    mask.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(z0, z1)
+    assert torch.equal(z1[:, C:], torch.full((rows, ld - C), 7.0, device=DEV))     # padding untouched
+    bits = (z1[:, :C] > 0).view(rows, C // 4, 4).to(torch.uint8)
+    want = bits[..., 0] | (bits[..., 1] << 1) | (bits[..., 2] << 2) | (bits[..., 3] << 3)
+    assert torch.equal(mask, want)
+    # a NULL mask is refused
+    assert hip_lib.gs_bn_apply_mask(x.data_ptr(), rows, C, ld, coeffs.data_ptr(), rp, rl, z1.data_ptr(), ld,
+                                    None, st) != 0
+
+
 def _nhwc(t):
     return t.to(DEV).contiguous(memory_format=torch.channels_last)
 
@@ -609,10 +637,14 @@ def test_bn_backward_reduction_in_dgrad_epilogue(hip_lib, shape, monkeypatch):
     layer = layer.to(DEV).train()
     x = torch.randn(n, 32, h, w)
     gz = torch.randn(n, 4 * planes, h, w)
-    results, counts = [], []
-    for fuse in (True, False):
+    results, counts, mask_counts = [], [], []
+    # (fused with the ReLU mask of bn3 as bytes -- gs_bn_bwd_fuse mode 3, the default; fused with the
+    # mask read from the activation -- mode 2; unfused)
+    for fuse, mask_bytes in ((True, True), (True, False), (False, True)):
         monkeypatch.setattr(ops, "BNBWD_FUSE", fuse)
+        monkeypatch.setattr(ops, "RELU_MASK_BYTES", mask_bytes)
         ops.BNBWD_FUSED_COUNT = 0
+        ops.BNBWD_FUSED_MASK_COUNT = 0
         for p in layer.parameters():
             p.grad = None
         for m in layer.modules():
@@ -623,10 +655,14 @@ def test_bn_backward_reduction_in_dgrad_epilogue(hip_lib, shape, monkeypatch):
         z = layer(xg)
         z.backward(gz.to(DEV).contiguous(memory_format=torch.channels_last))
         counts.append(ops.BNBWD_FUSED_COUNT)
+        mask_counts.append(ops.BNBWD_FUSED_MASK_COUNT)
         results.append([z.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
     # block 0: bn1 (conv2 owns), bn2 (conv3 owns); blocks 1, 2: + bn3 of the block before (conv1 owns).
     # (second shape: some of the dgrads are split along K — there the slab reduce does the fusion)
-    assert counts == [2 + 3 + 3, 0]
-    assert torch.equal(results[0][0], results[1][0])
-    for a, b in zip(results[0][1:], results[1][1:]):
+    assert counts == [2 + 3 + 3, 2 + 3 + 3, 0]
+    assert mask_counts == [2, 0, 0]          # the two bn3 masks came from the bytes
+    for a, b in zip(results[0], results[1]):
+        assert torch.equal(a, b)             # the same mask, the same arithmetic: bit for bit
+    assert torch.equal(results[0][0], results[2][0])
+    for a, b in zip(results[0][1:], results[2][1:]):
         assert rel_err(a, b) < 2e-5
