@@ -408,6 +408,10 @@ def main():
         metas = [fixed_meta] if fixed_meta is not None else list(sampler.model_samplers[0].anchors)
         graphs_built = runner.prepare_graphs(metas, make_batch(bs, size[0], size[1], 19, 12345, dev))
 
+    if os.environ.get("GS_MAIN_PRIORITY"):   # diagnostics: the training stream above the side stream
+        hp = torch.cuda.Stream(device=dev, priority=-1)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     for _ in range(args.warmup):
         runner.train_iter(next(loader))
     torch.cuda.synchronize()
