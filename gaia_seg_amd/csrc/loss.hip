@@ -132,6 +132,9 @@ __global__ __launch_bounds__(256) void ce_final_kernel(const double* __restrict_
 }
 
 // One workgroup per low-resolution pixel (n, y, x); classes in chunks of CCH kept in registers.
+// blockDim.x = 64, 128 or 256, about one full-resolution pixel of the support per thread
+// (gs_ce_backward): at config 4's 193 -> 769 the support is ~8 x 8 pixels, and 256 threads per
+// low-resolution pixel left three of four waves with nothing but the reductions (r03: 1988 us).
 constexpr int CCH = 32;
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const CeArgs a, const float* __restrict__ logits,
                                                      const int64_t* __restrict__ labels,
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const CeArgs a, const float
   dst_range(x, a.sw, a.d.W, xlo, xhi);
   const int nx = xhi - xlo + 1, npx = (yhi - ylo + 1) * nx;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nthr = blockDim.x, nwave = nthr >> 6;
   float* orow = dlogits + ((long)(n * a.d.h + y) * a.d.w + x) * ld_d;
 
   for (int c0 = 0; c0 < a.d.Cls; c0 += CCH) {
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const CeArgs a, const float
     float acc[CCH];
 #pragma unroll
     for (int c = 0; c < CCH; ++c) acc[c] = 0.f;
-    for (int q = threadIdx.x; q < npx; q += 256) {
+    for (int q = threadIdx.x; q < npx; q += nthr) {
       const int Y = ylo + q / nx, X = xlo + q % nx;
       const Lerp ly = lerp_coord(Y, a.sh, a.d.h, a.d.align_corners);
       const Lerp lx = lerp_coord(X, a.sw, a.d.w, a.d.align_corners);
@@ -192,17 +196,21 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const CeArgs a, const float
     }
 #pragma unroll
     for (int c = 0; c < CCH; ++c) {
-      const float v = wave_sum(acc[c]);
-      if (lane == 0) sh[wave][c] = v;
+      if (c < nc) {   // (block-uniform: 19 of the 32 slots carry a class at Cityscapes)
+        const float v = wave_sum(acc[c]);
+        if (lane == 0) sh[wave][c] = v;
+      }
     }
     __syncthreads();
-    if (threadIdx.x < CCH && threadIdx.x < nc)
-      orow[c0 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] +
-                               sh[3][threadIdx.x];
+    if (threadIdx.x < CCH && threadIdx.x < nc) {
+      float v = sh[0][threadIdx.x];               // wave order: fixed for a given block size
+      for (int wv = 1; wv < nwave; ++wv) v += sh[wv][threadIdx.x];
+      orow[c0 + threadIdx.x] = v;
+    }
     __syncthreads();
   }
   // zero the padding columns Cls..ld_d-1
-  for (int c = a.d.Cls + threadIdx.x; c < ld_d; c += 256) orow[c] = 0.f;
+  for (int c = a.d.Cls + threadIdx.x; c < ld_d; c += nthr) orow[c] = 0.f;
 }
 
 
@@ -429,7 +437,10 @@ extern "C" int gs_ce_backward(const gs_ce_desc* d, const float* logits, const in
   if (rc) return rc;
   if (!logits || !labels || !lse || !dlogits) return GS_E_NULL;
   if (ld_d < d->Cls) return GS_E_BADARG;
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(d->N * d->h * d->w), dim3(256), 0, as_stream(stream), a,
+  // support of a low-resolution pixel: ~(2 H/h) x (2 W/w) full-resolution pixels
+  const long sup = (2L * d->H / d->h + 1) * (2L * d->W / d->w + 1);
+  const int threads = sup > 128 ? 256 : sup > 64 ? 128 : 64;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(d->N * d->h * d->w), dim3(threads), 0, as_stream(stream), a,
                      logits, labels, pixel_weight, class_weight, lse, grad_scale, dlogits, ld_d);
   return launch_status();
 }
