@@ -35,18 +35,37 @@ def set_random_seed(seed, deterministic=False):
         torch.cuda.manual_seed_all(seed)
 
 
-def build_dataloader(dataset_cfg, samples_per_gpu, seed=0, device="cuda", num_classes=19):
+def build_dataloader(dataset_cfg, samples_per_gpu, seed=0, device="cuda", num_classes=19,
+                     workers_per_gpu=2, train=True):
+    """mmseg ``build_dataset`` + ``build_dataloader(..., dist, seed, drop_last=True)``
+    (gaiaseg/apis/train.py:74-84, tools/train_supernet.py:197) for this path: a config dict naming a
+    registered file-backed dataset (``CityscapesDataset19`` of the in-tree configs, ``CityscapesDataset``,
+    ``CustomDataset``) becomes a loader whose transforms run on the GPU; ``SyntheticSegDataset`` gives
+    the seeded synthetic batches; anything else that is already an iterable of batches passes through."""
     if isinstance(dataset_cfg, (list, tuple)):
+        if len(dataset_cfg) != 1:
+            raise NotImplementedError("concatenated datasets (%d entries)" % len(dataset_cfg))
         dataset_cfg = dataset_cfg[0]
     if isinstance(dataset_cfg, dict):
         t = dataset_cfg.get("type")
-        if t != "SyntheticSegDataset":
-            raise NotImplementedError(
-                "dataset type %r: only SyntheticSegDataset ships with this build (no dataset is "
-                "available offline); pass an iterable of batches for real data" % t)
-        return SyntheticLoader(samples_per_gpu, tuple(dataset_cfg["size"]),
-                               dataset_cfg.get("num_classes", num_classes), seed=seed,
-                               rank=gdist.rank(), device=device)
+        if t == "SyntheticSegDataset":
+            return SyntheticLoader(samples_per_gpu, tuple(dataset_cfg["size"]),
+                                   dataset_cfg.get("num_classes", num_classes), seed=seed,
+                                   rank=gdist.rank(), device=device)
+        from ..datasets import (DATASETS, FileBatchLoader, FileEvalLoader, build_dataset,
+                                eval_pipeline_kwargs, train_pipeline_kwargs)
+        if t not in DATASETS:
+            raise NotImplementedError("dataset type %r is not registered (have %s and "
+                                      "SyntheticSegDataset)" % (t, sorted(DATASETS.module_dict)))
+        ds = build_dataset(dataset_cfg)
+        if train:
+            return FileBatchLoader(ds, samples_per_gpu, train_pipeline_kwargs(ds.pipeline),
+                                   workers_per_gpu=workers_per_gpu, seed=seed, rank=gdist.rank(),
+                                   world=gdist.world_size(), device=device)
+        tk = eval_pipeline_kwargs(ds.pipeline)
+        return FileEvalLoader(ds, samples_per_gpu, tk["img_scale"], tk["mean"], tk["std"], tk["to_rgb"],
+                              workers_per_gpu=workers_per_gpu, rank=gdist.rank(),
+                              world=gdist.world_size(), device=device)
     return dataset_cfg  # already an iterable of batches
 
 
@@ -93,7 +112,8 @@ def train_segmentor(model, train_sampler, val_sampler, dataset, cfg, distributed
         ev = dict(cfg.evaluation)
         val_cfg = cfg.data.get("val") or cfg.data["train"]
         val_loader = build_dataloader(val_cfg, cfg.data["samples_per_gpu"], seed=12345,
-                                      device=device)
+                                      device=device, train=cfg.data.get("val") is None,
+                                      workers_per_gpu=cfg.data.get("workers_per_gpu", 2))
         runner.register_hook(CrossArchEvalHook(val_loader, val_sampler,
                                                interval=ev.get("interval", 8000),
                                                num_batches=ev.get("num_batches", 4),
@@ -105,6 +125,6 @@ def train_segmentor(model, train_sampler, val_sampler, dataset, cfg, distributed
     from .test import apply_bn_calibration
     apply_bn_calibration(model, cfg.get("caliberate_bn"), "train")   # gaiaseg/apis/train.py:177-184
     loader = build_dataloader(dataset, cfg.data["samples_per_gpu"], seed=cfg.get("seed") or 0,
-                              device=device)
+                              device=device, workers_per_gpu=cfg.data.get("workers_per_gpu", 2))
     runner.run([loader], cfg.get("workflow", [("train", 1)]))
     return runner

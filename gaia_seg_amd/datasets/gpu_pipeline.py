@@ -108,7 +108,8 @@ class GpuTrainPipeline:
     def __init__(self, crop_size=(512, 1024), img_scale=(2048, 1024), ratio_range=(0.5, 2.0),
                  cat_max_ratio=0.75, flip_ratio=0.5, photometric=True,
                  mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True,
-                 pad_val=0.0, seg_pad_val=255, ignore_index=255, seed=None, device="cuda"):
+                 pad_val=0.0, seg_pad_val=255, ignore_index=255, seed=None, device="cuda",
+                 src_is_rgb=False):
         self.cfg = dict(crop_size=tuple(crop_size), img_scale=tuple(img_scale),
                         ratio_range=tuple(ratio_range), cat_max_ratio=cat_max_ratio,
                         flip_ratio=flip_ratio, photometric=photometric, ignore_index=ignore_index)
@@ -116,6 +117,7 @@ class GpuTrainPipeline:
         self.pad_val, self.seg_pad_val = float(pad_val), int(seg_pad_val)
         self.rng = np.random.RandomState(seed)
         self.device = torch.device(device)
+        self.src_is_rgb = bool(src_is_rgb)   # decoded by Pillow (RGB) instead of cv2.imread (BGR)
 
     def descriptor(self, h, w, p, src_is_rgb=False):
         d = _lib.AugmentDesc()
@@ -135,8 +137,10 @@ class GpuTrainPipeline:
         d.pad_val, d.seg_pad_val = self.pad_val, self.seg_pad_val
         return d
 
-    def sample(self, img, label, out_img, out_label, params=None, src_is_rgb=False):
+    def sample(self, img, label, out_img, out_label, params=None, src_is_rgb=None):
         """Augment one decoded sample into row slices of the batch tensors; returns the params."""
+        if src_is_rgb is None:
+            src_is_rgb = self.src_is_rgb
         img = img.to(self.device, non_blocking=True).contiguous()
         label = label.to(self.device, non_blocking=True).contiguous()
         if img.dtype != torch.uint8 or label.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
@@ -163,3 +167,40 @@ class GpuTrainPipeline:
                               scale_factor=p["res_h"] / s[0].shape[0],
                               filename=s[2] if len(s) > 2 else "sample_%d" % i))
         return dict(img=imgs, img_metas=metas, gt_semantic_seg=gts)
+
+    def test_batch(self, samples, img_scale):
+        """The single-scale test pipeline (LoadImageFromFile, Resize(keep_ratio) to ``img_scale``,
+        Normalize; configs/_dynamic_/models/pspnet_ar50to101v2_gsync.py:76-93) for samples of ONE
+        size: img fp32 [N, 3, h', w'] through the same kernel (no crop, flip or distortion), and the
+        label maps at their ORIGINAL size (predictions are rescaled to ``ori_shape`` before they are
+        compared)."""
+        h, w = int(samples[0][0].shape[0]), int(samples[0][0].shape[1])
+        for s in samples:
+            if tuple(s[0].shape[:2]) != (h, w):
+                raise ValueError("test_batch needs samples of one size (got %s and %s)"
+                                 % ((h, w), tuple(s[0].shape[:2])))
+        rh, rw = rescale_size(h, w, img_scale) if img_scale is not None else (h, w)
+        n = len(samples)
+        imgs = torch.empty((n, 3, rh, rw), dtype=torch.float32, device=self.device)
+        scratch = torch.empty((rh, rw), dtype=torch.int64, device=self.device)
+        gts, metas = [], []
+        p = dict(res_h=rh, res_w=rw, crop_y=0, crop_x=0, crop_h=rh, crop_w=rw, flip=False)
+        for i, s in enumerate(samples):
+            img = s[0].to(self.device, non_blocking=True).contiguous()
+            label = s[1]
+            dummy = label if label is not None else torch.zeros((h, w), dtype=torch.uint8)
+            dummy = dummy.to(self.device, non_blocking=True).contiguous()
+            d = self.descriptor(h, w, p, self.src_is_rgb)
+            d.out_h, d.out_w = rh, rw
+            _lib.check(_lib.load().gs_seg_augment(ctypes.byref(d), img.data_ptr(), dummy.data_ptr(),
+                                                  imgs[i].data_ptr(), scratch.data_ptr(),
+                                                  current_stream_ptr()), "gs_seg_augment")
+            if label is not None:
+                gts.append(dummy.to(torch.int64))
+            metas.append(dict(ori_shape=(h, w, 3), img_shape=(rh, rw, 3), pad_shape=(rh, rw, 3),
+                              flip=False, flip_direction="horizontal", scale_factor=rh / h,
+                              filename=s[2] if len(s) > 2 else "sample_%d" % i))
+        out = dict(img=imgs, img_metas=metas)
+        if gts:
+            out["gt_semantic_seg"] = torch.stack(gts).unsqueeze(1)
+        return out

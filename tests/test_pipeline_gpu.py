@@ -1,5 +1,7 @@
 """GPU input pipeline (gs_seg_augment) against the oracle's numpy restatement of the reference's
 train_pipeline transforms, on the same random decisions."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -69,3 +71,108 @@ def test_pipeline_draws_and_trains(hip_lib):
     lab = batch["gt_semantic_seg"].cpu()
     assert int(((lab < 0) | ((lab > 18) & (lab != 255))).sum()) == 0
     assert bool(torch.isfinite(batch["img"]).all())
+
+
+# ---- file-backed datasets through the GPU pipeline ------------------------------------------------
+def _small_pipeline(crop=(64, 96), scale=(160, 96)):
+    return [dict(type="LoadImageFromFile"), dict(type="LoadAnnotations"),
+            dict(type="Resize", img_scale=scale, ratio_range=(0.5, 2.0)),
+            dict(type="RandomCrop", crop_size=crop, cat_max_ratio=0.75),
+            dict(type="RandomFlip", flip_ratio=0.5), dict(type="PhotoMetricDistortion"),
+            dict(type="Normalize", mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True),
+            dict(type="Pad", size=crop, pad_val=0, seg_pad_val=255),
+            dict(type="DefaultFormatBundle"), dict(type="Collect", keys=["img", "gt_semantic_seg"])]
+
+
+def test_file_loader_batches_equal_the_oracle_pipeline_on_the_decoded_files(hip_lib, tmp_path):
+    """CityscapesDataset19 config dict -> build_dataloader -> batches: every sample equals the oracle's
+    numpy transforms applied to the decoded PNG (converted to the BGR order cv2.imread gives, which is
+    what the oracle restates) with the decisions the loader's pipeline drew; the stream is the seeded
+    DistributedSampler order (configs/_dynamic_/models/pspnet_ar50to101v2_gsync.py:95-118)."""
+    from gaia_seg_amd.apis.train import build_dataloader
+    from gaia_seg_amd.datasets import draw_train_params, epoch_indices
+    from oracle.pipeline import train_sample
+    from test_datasets import make_cityscapes
+    truth = make_cityscapes(str(tmp_path), cities=(("a", 3), ("b", 3)), size=(96, 160))
+    cfg = [dict(type="CityscapesDataset19", data_root=str(tmp_path), img_dir="leftImg8bit/train",
+                ann_dir="gtFine/train", pipeline=_small_pipeline())]
+    ld = build_dataloader(cfg, 2, seed=4, device="cuda", workers_per_gpu=2)
+    names = sorted(truth)
+    rng = np.random.RandomState(4 * 1000003)          # the loader's pipeline seed at rank 0
+    order = epoch_indices(6, 0, 4, 0, 1) + epoch_indices(6, 1, 4, 0, 1)
+    k = 0
+    for _ in range(5):                                 # crosses the epoch boundary (3 batches / epoch)
+        batch = next(ld)
+        assert tuple(batch["img"].shape) == (2, 3, 64, 96) and batch["img"].is_cuda
+        for j in range(2):
+            rgb, lab = truth[names[order[k]]]
+            k += 1
+            p = draw_train_params(rng, 96, 160, ld.pipeline.cfg, torch.from_numpy(lab))
+            want_img, want_lab = train_sample(rgb[:, :, ::-1].copy(), lab, p, crop_size=(64, 96))
+            assert batch["img_metas"][j]["filename"].endswith(names[order[k - 1]])
+            assert np.array_equal(batch["gt_semantic_seg"][j, 0].cpu().numpy(), want_lab)
+            assert float(np.abs(batch["img"][j].cpu().numpy() - want_img).max()) <= 1e-6
+    ld.close()
+
+
+def test_eval_loader_normalises_whole_images_and_keeps_original_labels(hip_lib, tmp_path):
+    from gaia_seg_amd.apis.train import build_dataloader
+    from oracle.pipeline import train_sample
+    from test_datasets import TEST_PIPELINE, make_cityscapes
+    truth = make_cityscapes(str(tmp_path), cities=(("a", 2), ("b", 1)), size=(64, 128), split="val")
+    pipe = [dict(TEST_PIPELINE[0]), dict(TEST_PIPELINE[1], img_scale=(128, 64))]
+    cfg = dict(type="CityscapesDataset", data_root=str(tmp_path), img_dir="leftImg8bit/val",
+               ann_dir="gtFine/val", pipeline=pipe)
+    ld = build_dataloader(cfg, 2, device="cuda", train=False)
+    names = sorted(truth)
+    b0, b1 = next(ld), next(ld)
+    assert tuple(b0["img"].shape) == (2, 3, 64, 128) and tuple(b1["img"].shape) == (2, 3, 64, 128)
+    seen = [m["filename"] for m in b0["img_metas"] + b1["img_metas"]]
+    assert [s.split(os.sep)[-1] for s in seen] == [names[i].split(os.sep)[-1] for i in (0, 1, 2, 0)]   # cycles
+    p = dict(res_h=64, res_w=128, crop_y=0, crop_x=0, crop_h=64, crop_w=128, flip=False, pm_enable=False)
+    for j in range(2):
+        rgb, lab = truth[names[j]]
+        want_img, _ = train_sample(rgb[:, :, ::-1].copy(), lab, p, crop_size=(64, 128))
+        assert float(np.abs(b0["img"][j].cpu().numpy() - want_img).max()) <= 1e-6
+        assert np.array_equal(b0["gt_semantic_seg"][j, 0].cpu().numpy(), lab.astype(np.int64))
+        assert b0["img_metas"][j]["ori_shape"] == (64, 128, 3)
+    ld.close()
+
+
+def test_train_cli_from_a_file_backed_config(hip_lib, tmp_path):
+    """tools/train_supernet.py with the in-tree FCN supernet config whose ``data`` block names
+    CityscapesDataset19 directories, as the reference's config does
+    (configs/_dynamic_/models/pspnet_ar50to101v2_gsync.py:95-135): trains and runs the cross-arch
+    evaluation from PNG files."""
+    import subprocess
+    import sys
+    from test_datasets import make_cityscapes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = str(tmp_path / "cityscapes")
+    make_cityscapes(data, cities=(("a", 3), ("b", 2)), size=(192, 320))
+    make_cityscapes(data, cities=(("v", 2),), size=(192, 320), split="val", seed=9)
+    norm = "dict(type='Normalize', mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)"
+    cfg = tmp_path / "fcn_files.py"
+    cfg.write_text(
+        "_base_ = [%r]\n" % os.path.join(root, "configs", "supernet", "fcn_ar50to101v2.py") +
+        "crop_size = (128, 256)\n"
+        "data = dict(_delete_=True, samples_per_gpu=2, workers_per_gpu=2,\n"
+        "    train=[dict(type='CityscapesDataset19', data_root=%r, img_dir='leftImg8bit/train',\n" % data +
+        "                ann_dir='gtFine/train', pipeline=[dict(type='LoadImageFromFile'), dict(type='LoadAnnotations'),\n"
+        "                    dict(type='Resize', img_scale=(320, 192), ratio_range=(0.5, 2.0)),\n"
+        "                    dict(type='RandomCrop', crop_size=(128, 256), cat_max_ratio=0.75),\n"
+        "                    dict(type='RandomFlip', flip_ratio=0.5), dict(type='PhotoMetricDistortion'), %s,\n" % norm +
+        "                    dict(type='Pad', size=(128, 256), pad_val=0, seg_pad_val=255),\n"
+        "                    dict(type='DefaultFormatBundle'), dict(type='Collect', keys=['img', 'gt_semantic_seg'])])],\n"
+        "    val=dict(type='CityscapesDataset19', data_root=%r, img_dir='leftImg8bit/val', ann_dir='gtFine/val',\n" % data +
+        "             pipeline=[dict(type='LoadImageFromFile'), dict(type='MultiScaleFlipAug', img_scale=(320, 192), flip=False,\n"
+        "                 transforms=[dict(type='Resize', keep_ratio=True), dict(type='RandomFlip'), %s,\n" % norm +
+        "                             dict(type='ImageToTensor', keys=['img']), dict(type='Collect', keys=['img'])])]))\n")
+    cmd = [sys.executable, os.path.join(root, "tools", "train_supernet.py"), str(cfg), "--work-dir",
+           str(tmp_path / "work"), "--seed", "0", "--max-iters", "4", "--cfg-options", "log_config.interval=2",
+           "checkpoint_config.interval=100", "evaluation.interval=4", "evaluation.num_batches=1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = res.stderr + res.stdout
+    assert "Iter [4/4]" in out and "decode.loss_seg" in out
+    assert out.count("mIoU") >= 3 and "R101" in out, out[-2000:]
