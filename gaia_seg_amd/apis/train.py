@@ -36,7 +36,7 @@ def set_random_seed(seed, deterministic=False):
 
 
 def build_dataloader(dataset_cfg, samples_per_gpu, seed=0, device="cuda", num_classes=19,
-                     workers_per_gpu=2, train=True):
+                     workers_per_gpu=2, train=True, device_cache_gb=None):
     """mmseg ``build_dataset`` + ``build_dataloader(..., dist, seed, drop_last=True)``
     (gaiaseg/apis/train.py:74-84, tools/train_supernet.py:197) for this path: a config dict naming a
     registered file-backed dataset (``CityscapesDataset19`` of the in-tree configs, ``CityscapesDataset``,
@@ -58,14 +58,17 @@ def build_dataloader(dataset_cfg, samples_per_gpu, seed=0, device="cuda", num_cl
             raise NotImplementedError("dataset type %r is not registered (have %s and "
                                       "SyntheticSegDataset)" % (t, sorted(DATASETS.module_dict)))
         ds = build_dataset(dataset_cfg)
+        # decoded uint8 samples kept in HBM (``data.device_cache_gb``, a key of this build; None = the
+        # loaders' defaults, 0 = off)
+        extra = {} if device_cache_gb is None else dict(device_cache_bytes=int(device_cache_gb * (1 << 30)))
         if train:
             return FileBatchLoader(ds, samples_per_gpu, train_pipeline_kwargs(ds.pipeline),
                                    workers_per_gpu=workers_per_gpu, seed=seed, rank=gdist.rank(),
-                                   world=gdist.world_size(), device=device)
+                                   world=gdist.world_size(), device=device, **extra)
         tk = eval_pipeline_kwargs(ds.pipeline)
         return FileEvalLoader(ds, samples_per_gpu, tk["img_scale"], tk["mean"], tk["std"], tk["to_rgb"],
                               workers_per_gpu=workers_per_gpu, rank=gdist.rank(),
-                              world=gdist.world_size(), device=device)
+                              world=gdist.world_size(), device=device, **extra)
     return dataset_cfg  # already an iterable of batches
 
 
@@ -113,7 +116,8 @@ def train_segmentor(model, train_sampler, val_sampler, dataset, cfg, distributed
         val_cfg = cfg.data.get("val") or cfg.data["train"]
         val_loader = build_dataloader(val_cfg, cfg.data["samples_per_gpu"], seed=12345,
                                       device=device, train=cfg.data.get("val") is None,
-                                      workers_per_gpu=cfg.data.get("workers_per_gpu", 2))
+                                      workers_per_gpu=cfg.data.get("workers_per_gpu", 2),
+                                      device_cache_gb=cfg.data.get("device_cache_gb"))
         runner.register_hook(CrossArchEvalHook(val_loader, val_sampler,
                                                interval=ev.get("interval", 8000),
                                                num_batches=ev.get("num_batches", 4),
@@ -125,6 +129,7 @@ def train_segmentor(model, train_sampler, val_sampler, dataset, cfg, distributed
     from .test import apply_bn_calibration
     apply_bn_calibration(model, cfg.get("caliberate_bn"), "train")   # gaiaseg/apis/train.py:177-184
     loader = build_dataloader(dataset, cfg.data["samples_per_gpu"], seed=cfg.get("seed") or 0,
-                              device=device, workers_per_gpu=cfg.data.get("workers_per_gpu", 2))
+                              device=device, workers_per_gpu=cfg.data.get("workers_per_gpu", 2),
+                              device_cache_gb=cfg.data.get("device_cache_gb"))
     runner.run([loader], cfg.get("workflow", [("train", 1)]))
     return runner

@@ -112,7 +112,19 @@ def test_file_loader_batches_equal_the_oracle_pipeline_on_the_decoded_files(hip_
             assert batch["img_metas"][j]["filename"].endswith(names[order[k - 1]])
             assert np.array_equal(batch["gt_semantic_seg"][j, 0].cpu().numpy(), want_lab)
             assert float(np.abs(batch["img"][j].cpu().numpy() - want_img).max()) <= 1e-6
+    # the second epoch came out of the device cache: six files decoded once each (plus what the
+    # prefetcher had in flight when the first epoch ended)
+    assert len(ld._pre.cache) == 6 and ld._pre.decoded <= 6 + 4
+    before = ld._pre.decoded
+    for _ in range(3):
+        next(ld)
+    assert ld._pre.decoded == before
     ld.close()
+    off = build_dataloader(cfg, 2, seed=4, device="cuda", device_cache_gb=0)
+    for _ in range(4):
+        next(off)
+    assert not off._pre.cache and off._pre.decoded == 8
+    off.close()
 
 
 def test_eval_loader_normalises_whole_images_and_keeps_original_labels(hip_lib, tmp_path):
