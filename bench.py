@@ -537,11 +537,12 @@ def main():
                           "inside every timed step" if args.data == "pipeline" else
                           "resident synthetic fp32 batches"),
                 "device_mallocs_in_timed_steps": int(seg_new),
-                "contraction": "fp32 MFMA (forward, weight gradient); stride-1 data gradients: six bf16 "
-                               "MFMAs over an exact three-way bf16 split of both operands, fp32 "
-                               "accumulation (GS_X3=0 turns it off; GS_X3_FWD=1 puts the 3x3 forwards on "
-                               "it too -- off by default, it costs parity margin: DESIGN.md section 11); "
-                               "the measured FLOP shares are in roofline_step.flop_share_by_k_loop",
+                "contraction": "fp32 MFMA (forward, weight gradient); stride-1 data gradients and the "
+                               "split-K 3x3 forwards: six bf16 MFMAs over an exact three-way bf16 split "
+                               "of both operands, fp32 accumulation (GS_X3=0 / GS_X3_FWD=0 turn them "
+                               "off; the unsplit forwards stay on the fp32 MFMA for parity margin: "
+                               "DESIGN.md section 11); the measured FLOP shares are in "
+                               "roofline.flop_share_by_k_loop and roofline_step.flop_share_by_k_loop",
                 "step_graphs": dict(runner.graph_stats, built_at_startup=graphs_built,
                                     what="HIP-graph replay of recurring subnets' whole training "
                                          "step (same kernels as the eager step); counts cover "

@@ -65,7 +65,7 @@ extern "C" int gs_debug_k3_flops(double* flops, int32_t reset) {
 
 extern "C" int gs_debug_set_x3_fwd(int32_t mode) {
   if (mode < -1 || mode > 2) return GS_E_BADARG;
-  gs::g_x3_fwd = mode;           // -1: back to the environment's GS_X3_FWD (default 0)
+  gs::g_x3_fwd = mode;           // -1: back to the environment's GS_X3_FWD (default 3)
   return GS_OK;
 }
 

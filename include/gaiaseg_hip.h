@@ -541,11 +541,11 @@ int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset);
  * which MFMA path, so that its roofline fractions name the right bound.  Not thread-safe (one
  * launching thread at a time, like the training step). */
 int gs_debug_conv_launch_flops(double* flops, int32_t reset);
-/* Forward convolutions on the bf16x3 K loop: 0 = never (fp32 MFMA loops; the default: see
- * csrc/igemm_core.h x3_fwd_mode for the parity margin it costs), 1 = the shapes where it measured
- * ahead (3x3, not where the two-steps-per-barrier fp32 loop runs unsplit), 2 = every
- * launch the loop's gate admits (the operator tests), -1 = back to the GS_X3_FWD environment value.
- * Process-global. */
+/* Forward convolutions on the bf16x3 K loop: 0 = never (fp32 MFMA loops), 1 = the shapes where it
+ * measured ahead (3x3, not where the two-steps-per-barrier fp32 loop runs unsplit), 2 = every launch
+ * the loop's gate admits (the operator tests), 3 = the split-K 3x3s only (the default: see
+ * csrc/igemm_core.h x3_fwd_mode for the parity margins behind that choice), -1 = back to the
+ * GS_X3_FWD environment value.  Process-global. */
 int gs_debug_set_x3_fwd(int32_t mode);
 /* Compute units the planners assume: hipDeviceProp::multiProcessorCount of the current device, read
  * once at first use (256 on an MI355X; 256 is also assumed when no device is present). */
