@@ -599,7 +599,7 @@ def main():
                 "blended_bound": round(k3_bound, 1),
                 "frac_of_blended_bound": round(achieved / k3_bound, 4),
                 "bound_note": "`frac` = fp32-equivalent FLOPs / the 157.3 TF fp32 MFMA peak; the K3 launches "
-                              "dispatched to the bf16x3 loop (stage 1, split-K stages) are bounded by LDS "
+                              "dispatched to the bf16x3 loop (the split-K launches of stages 3-4) are bounded by LDS "
                               "bandwidth at %.0f fp32-equivalent TF instead: blended bound above"
                               % X3_LDS_BOUND_TFLOPS,
                 "measured_in": "a separate instrumented pass over the same %d draws (%.3f ms/step; "
