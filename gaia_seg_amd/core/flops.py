@@ -81,6 +81,25 @@ def psp_head_flops(head, c, h, w):
     return total + f
 
 
+def uper_head_flops(head, feats):
+    """DynamicUPerHead (gaiaseg/models/decode_heads/dynamic_uper_head.py:81-131): PPM + bottleneck on
+    the last level, one 1x1 lateral and one 3x3 fpn conv per other level at that level's size, the
+    3x3 fpn_bottleneck over the concatenated levels and the classifier at the first level's size."""
+    levels = [feats[i] for i in head.in_index]
+    c5, h5, w5 = levels[-1]
+    total = 0.0
+    scales = head.psp_modules.pool_scales
+    for s, ppm in zip(scales, head.psp_modules):
+        total += _conv(ppm[1].conv, c5, s, s)[0]
+    total += _conv(head.bottleneck.conv, c5 + len(scales) * head.channels, h5, w5)[0]
+    for (c, h, w), lat, fpn in zip(levels[:-1], head.lateral_convs, head.fpn_convs):
+        total += _conv(lat.conv, c, h, w)[0]
+        total += _conv(fpn.conv, head.channels, h, w)[0]
+    _, h0, w0 = levels[0]
+    f, _, cb, _, _ = _conv(head.fpn_bottleneck.conv, len(levels) * head.channels, h0, w0)
+    return total + f + _conv(head.conv_seg, cb, h0, w0)[0]
+
+
 def model_flops(model, h, w):
     """dict(backbone, backbone_3x3, decode, aux, total) in FLOPs per image for the current arch."""
     b, params, k3, feats = backbone_flops(model.backbone, h, w)
@@ -95,6 +114,8 @@ def model_flops(model, h, w):
             out[key] = fcn_head_flops(head, c, fh, fw)
         elif name == "DynamicPSPHead":
             out[key] = psp_head_flops(head, c, fh, fw)
+        elif name == "DynamicUPerHead":
+            out[key] = uper_head_flops(head, feats)
         else:
             out[key] = float("nan")
     out["total"] = sum(v for k, v in out.items() if k in ("backbone", "decode", "aux") and v == v)

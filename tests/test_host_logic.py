@@ -188,6 +188,31 @@ def test_closed_form_flops_match_baseline_table(psp_model):
         assert abs(f["decode"] / 1e9 - psp) < 0.06 and abs(f["aux"] / 1e9 - aux) < 0.06
 
 
+def test_closed_form_flops_of_the_uper_head():
+    """BASELINE config 4 (UPerNet, R101 anchor, 769 x 769; SURVEY.md section 8 a16: ~964 GF per image):
+    the head's closed form against the same sum written out from the level sizes
+    (dynamic_uper_head.py:81-131: PPM + bottleneck on C5, laterals and fpn convs on the other three
+    levels, fpn_bottleneck and the classifier at level 0)."""
+    from gaia_seg_amd.core.flops import model_flops
+    from gaia_seg_amd.models import build_segmentor
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "supernet", "upernet_ar50to101v2.py"))
+    model = build_segmentor(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg"))
+    anchors = {a["name"]: a for a in build_model_sampler(cfg.train_sampler).model_samplers[0].anchors}
+    model.manipulate_arch(fold_dict(anchors["R101"])["arch"])
+    f = model_flops(model, 769, 769)
+    lv = [(256, 193), (512, 97), (1024, 49), (2048, 25)]            # (channels, side) of C2..C5
+    ch = 512
+    want = sum(2.0 * s * s * ch * 2048 for s in (1, 2, 3, 6))       # PPM 1x1 convs
+    want += 2.0 * 25 * 25 * ch * (2048 + 4 * ch) * 9                # bottleneck 3x3
+    want += sum(2.0 * n * n * ch * c for c, n in lv[:3])            # laterals 1x1
+    want += sum(2.0 * n * n * ch * ch * 9 for _, n in lv[:3])       # fpn convs 3x3
+    want += 2.0 * 193 * 193 * ch * (4 * ch) * 9                     # fpn_bottleneck 3x3
+    want += 2.0 * 193 * 193 * 19 * ch                               # conv_seg
+    assert abs(f["decode"] - want) / want < 1e-12, (f["decode"], want)
+    assert abs(f["decode"] / 1e9 - 964) / 964 < 0.02                # SURVEY's rounded figure
+    assert f["total"] == f["backbone"] + f["decode"] + f["aux"]
+
+
 def test_bn_calibration_switches():
     """cfg.caliberate_bn: reset_stats before training (gaiaseg/apis/train.py:177-184) and
     use_minibatch_stats at test time (tools/test_supernet.py:190-198)."""
