@@ -1989,8 +1989,11 @@ static inline bool pair_loop_ok(const Plan& pl) {
          (long)pl.tiles_m * pl.tiles_n * pl.splits <= 3L * num_cu();
 }
 static inline bool x3_grid_ok(const Plan& pl, int min_ksteps_) {
+  // (r03 A/B: 32 instead of 48 puts the MIN anchor's split-K launches on the loop as well -- MIN +1 %,
+  // sampled mix +-0; kept at 48)
+  static const int split_min = env_int("GS_X3_SPLIT_MIN", 48);
   return min_ksteps_ > 0 && pl.bm == 64 && pl.nk_per_split >= min_ksteps_ &&
-         (pl.splits == 1 || pl.nk_per_split >= 48) &&
+         (pl.splits == 1 || pl.nk_per_split >= split_min) &&
          (long)pl.tiles_m * pl.tiles_n * pl.splits >= 2L * num_cu();
 }
 template <bool BTRANS>
