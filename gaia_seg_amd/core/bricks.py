@@ -362,8 +362,17 @@ def build_activation_layer(cfg):
 _NO_FUSED_CALLS = os.environ.get("GS_NO_FUSED_CALLS") is not None
 
 
+def fused_call_ok(conv, norm):
+    """conv -> norm can go through the one-call-per-direction entry (ops.conv_bn): a bias-free conv of a
+    width that is a multiple of 4 followed by a rank-local BatchNorm, not while extracting a subnet."""
+    return (conv._parameters["bias"] is None and conv.width_state % 4 == 0
+            and not conv.__dict__.get("_deploying", False)
+            and not norm.__dict__.get("_deploying", False) and not _NO_FUSED_CALLS
+            and not (norm.training and norm.sync is not None and norm._process_group() is not None))
+
+
 def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=None, defer=False,
-                owns_input_grad=False):
+                owns_input_grad=False, defer_residual=False):
     """conv -> norm (+ residual) (+ ReLU).  ``defer``: leave the BN + ReLU to the consumer's operand
     loaders where the fused path allows it (ops.conv_bn).  Rank-local BatchNorm after a bias-free conv goes through
     the one-call-per-direction library entry (ops.conv_bn); SyncBN with a process group, a conv
@@ -384,7 +393,8 @@ def conv_bn_act(tape, conv, norm, x, relu=False, residual=None, out=None, tag=No
                 cd["_layout_ptr"] = weight.data_ptr()
             return ops.conv_bn(tape, x, weight, c, bnp, conv.stride, conv.padding,
                                conv.dilation, relu=relu, residual=residual, out=out, tag=tag,
-                               defer=defer, owns_input_grad=owns_input_grad)
+                               defer=defer, owns_input_grad=owns_input_grad,
+                               defer_residual=defer_residual)
     y = conv.forward_act(tape, x, tag=tag)
     return norm.forward_act(tape, y, relu=relu, residual=residual, out=out)
 
@@ -515,46 +525,63 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
                 if isinstance(m, DynamicConv2d):
                     m.manipulate_width(width * self.expansion)
 
-    def forward_act(self, tape, x):
-        # the shortcut branch is evaluated first so that, in the reversed backward replay, its
-        # strided dgrad ACCUMULATES into x.g after conv1's dgrad wrote it: the parity classes of a
-        # stride-2 1x1 conv that have no tap then need no zero fill at all
+    def _shortcut_act(self, tape, x, defer_residual=False):
+        """The projection shortcut: [AvgPool2d,] 1x1 conv, norm (dynamic_res_layer.py:70-94).
+        ``defer_residual``: leave the norm to the residual add of norm3's apply pass."""
         identity = x
-        if self.downsample is not None:
-            members = list(self.downsample)
-            if isinstance(members[0], nn.AvgPool2d):
-                # avg_down (dynamic_res_layer.py:75-82): AvgPool2d(stride, ceil_mode=True,
-                # count_include_pad=False) in front of a stride-1 1x1 conv
-                pool = members.pop(0)
-                k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
-                st = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
-                if k != st or not pool.ceil_mode or pool.count_include_pad or pool.padding not in (0, (0, 0)):
-                    raise NotImplementedError("downsample AvgPool2d other than (k = stride, "
-                                              "ceil_mode=True, count_include_pad=False)")
-                identity = ops.avgpool_ceil(tape, identity, st) if st > 1 else identity
-            if (len(members) == 2 and isinstance(members[0], DynamicConv2d)
-                    and isinstance(members[1], DynamicBatchNorm2d)):
-                identity = conv_bn_act(tape, members[0], members[1], identity, relu=False)
-            else:
-                raise NotImplementedError("downsample branch %s: expected [AvgPool2d,] conv, norm"
-                                          % [type(m).__name__ for m in self.downsample])
+        members = list(self.downsample)
+        if isinstance(members[0], nn.AvgPool2d):
+            # avg_down (dynamic_res_layer.py:75-82): AvgPool2d(stride, ceil_mode=True,
+            # count_include_pad=False) in front of a stride-1 1x1 conv
+            pool = members.pop(0)
+            k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+            st = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
+            if k != st or not pool.ceil_mode or pool.count_include_pad or pool.padding not in (0, (0, 0)):
+                raise NotImplementedError("downsample AvgPool2d other than (k = stride, "
+                                          "ceil_mode=True, count_include_pad=False)")
+            identity = ops.avgpool_ceil(tape, identity, st) if st > 1 else identity
+        if (len(members) == 2 and isinstance(members[0], DynamicConv2d)
+                and isinstance(members[1], DynamicBatchNorm2d)):
+            return conv_bn_act(tape, members[0], members[1], identity, relu=False,
+                               defer_residual=defer_residual)
+        raise NotImplementedError("downsample branch %s: expected [AvgPool2d,] conv, norm"
+                                  % [type(m).__name__ for m in self.downsample])
+
+    def forward_act(self, tape, x):
         # bn1 -> conv2 / bn2 -> conv3 (ops.DEFER_EDGES): the normalised activation is never stored;
         # the consumer (forward and weight gradient) evaluates relu(bn(.)) in its operand loaders
         # owns_input_grad: the conv's data gradient is the last contribution to its input's gradient,
         # so its epilogue may also do the BatchNorm-backward reduction of the layer that produced
         # that input (conv2 / conv3 are the only consumers of theirs; conv1's input also feeds the
-        # identity branch, whose gradient is in place before conv1's backward runs — unless a
-        # projection shortcut consumes it too, which runs after conv1 in the reversed replay)
+        # identity branch or the projection shortcut, whose gradient is in place before conv1's
+        # backward runs, see below)
         hot = self.__dict__.get("_hot")   # (six nn.Module.__getattr__ walks per block otherwise)
         if hot is None:
             hot = self.__dict__["_hot"] = (self.conv1, self.norm1, self.conv2, self.norm2,
                                            self.conv3, self.norm3)
         conv1, norm1, conv2, norm2, conv3, norm3 = hot
         edges = ops.DEFER_EDGES
+        identity, br = x, None
+        if self.downsample is not None:
+            # The projection shortcut is independent of conv1 -> conv2: it runs on the branch stream
+            # beside them, forward and backward (ops.Branch).  In backward its data gradient is the
+            # FIRST writer of x.g (a strided one clears the pixel classes it has no tap for) and
+            # conv1's accumulates onto it after the join, so conv1 owns the input gradient here too.
+            # The shortcut's BatchNorm is applied inside norm3's apply pass (relu(bn3(y3) + bn_s(y_s))):
+            # its normalised output is never stored.
+            br = ops.Branch(tape, x.t.device, ops.BRANCH_SHORTCUT)
+            with br:
+                identity = self._shortcut_act(tape, x, ops.DEFER_SHORTCUT_BN
+                                              and fused_call_ok(conv3, norm3))
         out = conv_bn_act(tape, conv1, norm1, x, relu=True,
-                          defer="conv2" in edges, owns_input_grad=self.downsample is None)
+                          defer="conv2" in edges, owns_input_grad=True)
+        if br is not None:
+            br.record_backward_join(tape)
         out = conv_bn_act(tape, conv2, norm2, out, relu=True, tag="k3",   # SURVEY.md K3
                           defer="conv3" in edges, owns_input_grad=True)
+        if br is not None:
+            br.record_backward_body(tape)
+            br.join()
         return conv_bn_act(tape, conv3, norm3, out, relu=True, residual=identity,
                            owns_input_grad=True)
 

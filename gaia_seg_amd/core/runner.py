@@ -95,6 +95,7 @@ class ArenaOptimizerHook(Hook):
         finally:
             ops.DEFER_JOIN = False
         t1 = time.perf_counter() if prof is not None else 0.0
+        ops.join_branch_streams()      # (auxiliary head / shortcut work on the branch stream)
         runner.reducer.finish()
         scale = 1.0 / gdist.world_size()
         early, late = runner.split_ranges()

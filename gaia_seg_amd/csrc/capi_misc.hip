@@ -1,7 +1,7 @@
 // Library identification and error text of the gaiaseg_hip C-ABI.
 #include "common.h"
 
-extern "C" int gs_abi_version(void) { return 7; }
+extern "C" int gs_abi_version(void) { return 8; }
 
 extern "C" const char* gs_target_arch(void) { return "gfx950"; }
 
@@ -57,14 +57,14 @@ extern "C" int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset) {
 
 extern "C" int gs_debug_k3_flops(double* flops, int32_t reset) {
   for (int k = 0; k < GS_KLOOP_COUNT; ++k) {
-    if (flops) flops[k] = gs::g_k3_flops[k];
-    if (reset) gs::g_k3_flops[k] = 0.0;
+    if (flops) flops[k] = gs::flops_load(&gs::g_k3_flops[k]);
+    if (reset) gs::flops_store(&gs::g_k3_flops[k], 0.0);
   }
   return GS_OK;
 }
 
 extern "C" int gs_debug_set_x3_fwd(int32_t mode) {
-  if (mode < -1 || mode > 2) return GS_E_BADARG;
+  if (mode < -1 || mode > 3) return GS_E_BADARG;
   gs::g_x3_fwd = mode;           // -1: back to the environment's GS_X3_FWD (default 3)
   return GS_OK;
 }
@@ -80,8 +80,8 @@ extern "C" int gs_debug_set_stream_mode(int32_t mode) {
 extern "C" int gs_debug_conv_launch_flops(double* flops, int32_t reset) {
   for (int o = 0; o < 3; ++o)
     for (int k = 0; k < GS_KLOOP_COUNT; ++k) {
-      if (flops) flops[o * GS_KLOOP_COUNT + k] = gs::g_launch_flops[o][k];
-      if (reset) gs::g_launch_flops[o][k] = 0.0;
+      if (flops) flops[o * GS_KLOOP_COUNT + k] = gs::flops_load(&gs::g_launch_flops[o][k]);
+      if (reset) gs::flops_store(&gs::g_launch_flops[o][k], 0.0);
     }
   return GS_OK;
 }

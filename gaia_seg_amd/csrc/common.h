@@ -91,4 +91,21 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// Host-side diagnostic counters in double that several host threads add to (the forward thread and
+// the autograd thread both launch convolutions): compare-and-swap on the bit pattern.
+static inline double flops_load(const double* p) {
+  const unsigned long long b = __atomic_load_n(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED);
+  return __builtin_bit_cast(double, b);
+}
+static inline void flops_store(double* p, double v) {
+  __atomic_store_n(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED);
+}
+static inline void flops_add(double* p, double v) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  unsigned long long cur = __atomic_load_n(q, __ATOMIC_RELAXED), next;
+  do {
+    next = __builtin_bit_cast(unsigned long long, __builtin_bit_cast(double, cur) + v);
+  } while (!__atomic_compare_exchange_n(q, &cur, next, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+
 }  // namespace gs

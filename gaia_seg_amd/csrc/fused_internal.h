@@ -28,6 +28,11 @@ int bn_tile_finalize(const float* part, int np, int bm, long rows, int C, const 
                      const float* beta, float eps, float momentum, float* running_mean,
                      float* running_var, float* coeffs, hipStream_t st);
 
+// norm.hip: z = relu?((y - mean) * scale + beta + ((residual - rmean) * rscale + rbeta)), optional mask
+int bn_apply_resaff(const float* x, int64_t rows, int32_t C, int32_t ldx, const float* coeffs,
+                    const float* residual, int32_t ld_res, const float* rcoeffs, int32_t relu, float* y,
+                    int32_t ldy, uint8_t* mask, void* stream);
+
 // norm.hip: out[0..width) = fixed-order sum over nparts partial rows (quad-major layout)
 int bn_sum_partials(const float* part, int nparts, int width, float* out, hipStream_t st);
 

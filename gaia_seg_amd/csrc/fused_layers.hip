@@ -73,6 +73,9 @@ extern "C" int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const f
   if (rc != GS_OK) return rc;
   // z == NULL: the consumer applies relu(bn(y)) in its operand loader (gs_conv_desc::in_affine)
   if (!z) return residual ? GS_E_BADARG : GS_OK;
+  if (bn->residual_coeffs)
+    return bn_apply_resaff(y, rows, C, d->ldy, coeffs, residual, ld_res, bn->residual_coeffs, bn->relu,
+                           z, ldz, bn->relu_mask, stream);
   if (bn->relu_mask)
     return bn->relu ? gs_bn_apply_mask(y, rows, C, d->ldy, coeffs, residual, ld_res, z, ldz,
                                        bn->relu_mask, stream)

@@ -1803,11 +1803,13 @@ constexpr size_t kMaxSlabBytes = 96u << 20;
 // parity tests assert WHICH K loop produced the numbers they compare (capi_misc.hip owns the storage).
 extern thread_local gs_debug_launch g_last_launch;
 extern long long g_launch_counts[3][GS_KLOOP_COUNT][3];
-extern double g_launch_flops[3][GS_KLOOP_COUNT];   // algorithmic 2*M*N*K per (op, K loop); single-writer per stream thread
+extern double g_launch_flops[3][GS_KLOOP_COUNT];   // algorithmic 2*M*N*K per (op, K loop)
 extern double g_k3_flops[GS_KLOOP_COUNT];          // the same for the role-1 (bottleneck conv2) forward launches
+// (the forward thread, the autograd thread and their side-stream launches all add to these:
+// flops_add in common.h)
 static inline void note_launch(int op, int kloop, const Plan& pl, bool aff, int bw_mode,
                                double flops = 0.0) {
-  g_launch_flops[op][kloop] += flops;
+  flops_add(&g_launch_flops[op][kloop], flops);
   g_last_launch = gs_debug_launch{op, kloop, pl.bm, pl.bn, pl.splits, pl.nk_per_split, aff ? 1 : 0,
                                   bw_mode};
   // (mode 3 = mode 2's mask read from bytes: counted with mode 2, the record keeps the 3)
@@ -2034,7 +2036,7 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
   const bool pair = kloop == GS_KLOOP_FP32_PAIRS;
   note_launch(BTRANS ? GS_OP_DGRAD : GS_OP_FORWARD, kloop, pl, a.a_coeffs != nullptr, a.bw_mode,
               2.0 * a.M * (double)a.Nn * a.Ktot);
-  if (ROLE == 1 && !BTRANS) g_k3_flops[kloop] += 2.0 * a.M * (double)a.Nn * a.Ktot;
+  if (ROLE == 1 && !BTRANS) flops_add(&g_k3_flops[kloop], 2.0 * a.M * (double)a.Nn * a.Ktot);
   if (kloop == GS_KLOOP_BF16X3) {
     if constexpr (BTRANS) {
       if (pl.bn == 64)

@@ -181,8 +181,12 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
   bool bnb = false, bnb_split = false;
   // short-K 1x1 data gradients over many rows: the streaming kernel (igemm_stream.h); the fused
   // BatchNorm-backward sums come out as one partial per workgroup row range
-  const StreamPlan sp = (fast && ks == 1 && d->stride == 1) ? stream_plan(M, d->Ci, d->Co, true)
-                                                            : StreamPlan{0, 0, 0, 0, 0};
+  // (a padded 1x1 has Ho = H + 2 pad: the streaming kernel maps dy row m to dx row m, so it takes
+  // only the unpadded form; the tile kernels handle padding through base_h / base_w)
+  const bool same_rows = d->pad == 0 && d->H == d->Ho && d->W == d->Wo;
+  const StreamPlan sp = (fast && ks == 1 && d->stride == 1 && same_rows)
+                            ? stream_plan(M, d->Ci, d->Co, true, std::max<long>(d->x_sw, bw ? std::max(bw->ldy, bw->ldact) : 0))
+                            : StreamPlan{0, 0, 0, 0, 0};
   if (sp.ok) {
     if (bnbwd_fuse_ok(bw, d, workspace) && !no_bnb &&
         (size_t)2 * d->Ci * sp.row_groups * sizeof(float) <= workspace_bytes) {

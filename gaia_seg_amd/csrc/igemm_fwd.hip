@@ -34,7 +34,7 @@ static StreamPlan stream_fwd_plan(const gs_conv_desc* d, bool fast, const float*
     return none;
   if (d->x_sh != (int64_t)d->W * d->x_sw || d->x_sn != (int64_t)d->H * d->x_sh) return none;
   if (d->in_affine && d->Ci > 256) return none;
-  return stream_plan((long)d->N * d->Ho * d->Wo, d->Co, d->Ci, false);
+  return stream_plan((long)d->N * d->Ho * d->Wo, d->Co, d->Ci, false, d->ldy);
 }
 
 // Forward with the options of the fused conv+BN entry point (fused_layers.hip):
@@ -209,8 +209,10 @@ extern "C" int gs_debug_query_conv_launch(const gs_conv_desc* d, int32_t op, gs_
       pl = plan_dgrad(d);
       if (d->stride == 1 && fast) {
         kloop = rows_fast_kloop<true>(pl, false);
-        const StreamPlan sp = ks == 1 ? stream_plan((long)d->N * d->H * d->W, d->Ci, d->Co, true)
-                                      : StreamPlan{0, 0, 0, 0, 0};
+        const bool same_rows = d->pad == 0 && d->H == d->Ho && d->W == d->Wo;
+        const StreamPlan sp = (ks == 1 && same_rows)
+                                  ? stream_plan((long)d->N * d->H * d->W, d->Ci, d->Co, true, d->x_sw)
+                                  : StreamPlan{0, 0, 0, 0, 0};
         if (sp.ok && d->x_sc == 1) {
           kloop = GS_KLOOP_STREAM;
           pl = Plan{kStreamBM, sp.bnw, 1, (int)ceil_div(d->Co, BK), (int)ceil_div(d->Co, BK), sp.row_groups, sp.ncb};

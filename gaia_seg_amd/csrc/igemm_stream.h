@@ -62,12 +62,17 @@ static inline int stream_mode() {
 }
 
 // Host: which column-block width, how the rows are dealt to the workgroups.
-static inline StreamPlan stream_plan(long M, int Nn, int Cs, bool dgrad) {
+// ld_wide: the widest pixel stride among the buffers the epilogue addresses with 32-bit byte offsets
+// (the output, and the y / activation operands of the fused BatchNorm-backward epilogue).
+static inline StreamPlan stream_plan(long M, int Nn, int Cs, bool dgrad, long ld_wide) {
   StreamPlan sp{0, 0, 0, 0, 0};
   const int on = stream_mode();
   static const long min_rows = env_int("GS_STREAM_MIN_ROWS", 16384);
   if (!on || (Cs % BK) != 0 || (Nn & 3) || Cs > kStreamMaxK || M < min_rows || M >= (1L << 31) / 4)
     return sp;
+  // epilogue offsets 4u * (m * ld + col) and the buffer descriptors' record counts are 32-bit: the
+  // tile kernels (64-bit pointer arithmetic) take anything wider
+  if (M * std::max<long>(ld_wide, Nn) * 4 >= (1L << 31)) return sp;
   const int kpad = (int)ceil_div(Cs, 32) * 32;   // whole 32-channel chunks
   int best = 0, best_pad = 1 << 30;
   for (int bnw : {256, 128, 64}) {

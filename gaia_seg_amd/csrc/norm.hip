@@ -244,22 +244,36 @@ __global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(const float* __rest
 // MASKOUT (with RELU): also mask[r][cq] = one byte per channel quad, bit e set <=> y[r][4cq+e] > 0 --
 // what the fused BatchNorm-backward epilogue of the consumer's data gradient needs of y (mode 3 of
 // gs_bn_bwd_fuse): 1/16 of the bytes of reading y again.
-template <bool RES, bool RELU, bool MASKOUT = false>
+// RESAFF (with RES): res is the raw output of the projection shortcut's conv and rcoeffs that conv's
+// BatchNorm coefficients; the addend is (res - rmean) * rscale + rbeta — the same expression, in the
+// same order, as a separate apply pass of the shortcut would have stored.
+template <bool RES, bool RELU, bool MASKOUT = false, bool RESAFF = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, long rows, int C, int ldx,
                                                        const float* __restrict__ coeffs,
                                                        const float* res, int ld_res, float* y,
-                                                       int ldy, unsigned char* __restrict__ mask) {  // x / res / y may alias
+                                                       int ldy, unsigned char* __restrict__ mask,
+                                                       const float* __restrict__ rcoeffs = nullptr) {  // x / res / y may alias
   const int C4 = C >> 2;
   const ColMap m = col_map(C4);
   if (!m.active) return;
   const f32x4 scale = *reinterpret_cast<const f32x4*>(coeffs + m.cq * 4);
   const f32x4 beta = *reinterpret_cast<const f32x4*>(coeffs + C + m.cq * 4);
   const f32x4 mean = *reinterpret_cast<const f32x4*>(coeffs + 2 * C + m.cq * 4);
+  f32x4 rscale{1.f, 1.f, 1.f, 1.f}, rbeta{0.f, 0.f, 0.f, 0.f}, rmean{0.f, 0.f, 0.f, 0.f};
+  if (RESAFF) {
+    rscale = *reinterpret_cast<const f32x4*>(rcoeffs + m.cq * 4);
+    rbeta = *reinterpret_cast<const f32x4*>(rcoeffs + C + m.cq * 4);
+    rmean = *reinterpret_cast<const f32x4*>(rcoeffs + 2 * C + m.cq * 4);
+  }
   const long step = (long)gridDim.x * m.rpi;
   for (long r = (long)blockIdx.x * m.rpi + m.rr; r < rows; r += step) {
     f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + m.cq * 4);
     v = (v - mean) * scale + beta;
-    if (RES) v += *reinterpret_cast<const f32x4*>(res + r * ld_res + m.cq * 4);
+    if (RES) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(res + r * ld_res + m.cq * 4);
+      if (RESAFF) a = (a - rmean) * rscale + rbeta;
+      v += a;
+    }
     if (RELU) {
       if (MASKOUT)
         mask[r * C4 + m.cq] = (unsigned char)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) |
@@ -774,7 +788,7 @@ extern "C" int gs_bn_eval_coeffs(const float* running_mean, const float* running
 
 static int bn_apply_impl(const float* x, int64_t rows, int32_t C, int32_t ldx, const float* coeffs,
                          const float* residual, int32_t ld_res, int32_t relu, float* y, int32_t ldy,
-                         unsigned char* mask, void* stream) {
+                         unsigned char* mask, void* stream, const float* rcoeffs = nullptr) {
   int rc = check_rows(x, rows, C, ldx);
   if (rc) return rc;
   rc = check_rows(y, rows, C, ldy);
@@ -784,6 +798,21 @@ static int bn_apply_impl(const float* x, int64_t rows, int32_t C, int32_t ldx, c
   if (residual && (rc = check_rows(residual, rows, C, ld_res))) return rc;
   const dim3 grid(apply_grid(rows, C), (C >> 2) <= 256 ? 1 : (unsigned)ceil_div(C >> 2, 256));
   hipStream_t st = as_stream(stream);
+  if (rcoeffs) {   // the residual is a raw conv output with its own BatchNorm coefficients
+    if (!residual) return GS_E_BADARG;
+    if (!aligned16(rcoeffs)) return GS_E_ALIGN;
+    if (mask && !relu) return GS_E_BADARG;
+    if (mask)
+      hipLaunchKernelGGL((bn_apply_kernel<true, true, true, true>), grid, dim3(256), 0, st, x, (long)rows,
+                         C, ldx, coeffs, residual, ld_res, y, ldy, mask, rcoeffs);
+    else if (relu)
+      hipLaunchKernelGGL((bn_apply_kernel<true, true, false, true>), grid, dim3(256), 0, st, x, (long)rows,
+                         C, ldx, coeffs, residual, ld_res, y, ldy, (unsigned char*)nullptr, rcoeffs);
+    else
+      hipLaunchKernelGGL((bn_apply_kernel<true, false, false, true>), grid, dim3(256), 0, st, x, (long)rows,
+                         C, ldx, coeffs, residual, ld_res, y, ldy, (unsigned char*)nullptr, rcoeffs);
+    return launch_status();
+  }
 #define GS_APPLY(R, A)                                                                          \
   hipLaunchKernelGGL((bn_apply_kernel<R, A>), grid, dim3(256), 0, st, x, (long)rows, C, ldx,    \
                      coeffs, residual, ld_res, y, ldy, (unsigned char*)nullptr)
@@ -815,6 +844,16 @@ extern "C" int gs_bn_apply_mask(const float* x, int64_t rows, int32_t C, int32_t
   if (!mask) return GS_E_NULL;
   return bn_apply_impl(x, rows, C, ldx, coeffs, residual, ld_res, 1, y, ldy, mask, stream);
 }
+
+namespace gs {
+// gs_conv_bn_forward's apply pass (fused_layers.hip): residual with its own coefficients, optional mask
+int bn_apply_resaff(const float* x, int64_t rows, int32_t C, int32_t ldx, const float* coeffs,
+                    const float* residual, int32_t ld_res, const float* rcoeffs, int32_t relu, float* y,
+                    int32_t ldy, uint8_t* mask, void* stream) {
+  if (!rcoeffs) return GS_E_NULL;
+  return bn_apply_impl(x, rows, C, ldx, coeffs, residual, ld_res, relu, y, ldy, mask, stream, rcoeffs);
+}
+}  // namespace gs
 
 extern "C" int gs_bn_bwd_reduce(const float* dy, int32_t ld_dy, const float* x, int32_t ldx,
                                 const float* act, int32_t ld_act, int64_t rows, int32_t C,

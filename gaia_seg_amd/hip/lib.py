@@ -16,7 +16,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgaiaseg_hip.so")
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HipLibraryError(RuntimeError):
@@ -38,7 +38,7 @@ class BnArgs(Structure):
     _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p),
                 ("running_var", c_void_p), ("eps", c_float), ("momentum", c_float),
                 ("use_batch_stats", c_int32), ("update_running", c_int32), ("relu", c_int32),
-                ("reserved", c_int32), ("relu_mask", c_void_p)]
+                ("reserved", c_int32), ("relu_mask", c_void_p), ("residual_coeffs", c_void_p)]
 
 
 class BnBwdFuse(Structure):

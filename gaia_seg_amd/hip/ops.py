@@ -45,6 +45,7 @@ def _side_stream(dev):
 # "gradient ready" notifications of the reducer fire when the job is actually enqueued.
 WGRAD_BATCH = max(1, int(os.environ.get("GS_WGRAD_BATCH", "4")))
 _wgrad_jobs = []
+_wgrad_stream = None   # raw handle of the stream the queued jobs' operands were produced on
 
 
 _side_keep = []   # (dy, x) of weight-gradient kernels launched on the side stream, until the join
@@ -52,6 +53,11 @@ _side_keep = []   # (dy, x) of weight-gradient kernels launched on the side stre
 
 def queue_wgrad(d, x, dy, weight, gw, need, dev):
     """x: Act (kept alive until the launch), dy: gradient of the conv output, gw: weight.grad."""
+    global _wgrad_stream
+    st = current_stream_ptr()
+    if _wgrad_jobs and st != _wgrad_stream:
+        flush_wgrads()     # one event covers one batch: a batch never mixes producer streams
+    _wgrad_stream = st
     _wgrad_jobs.append((d, x, dy, weight, gw, need, dev))
     if len(_wgrad_jobs) >= WGRAD_BATCH:
         flush_wgrads()
@@ -67,7 +73,7 @@ def flush_wgrads():
     dev = jobs[0][6]
     side = _side_stream(dev)
     with torch.cuda.device(dev):
-        _lib.check(L.gs_stream_fork(current_stream_ptr(), side.cuda_stream), "gs_stream_fork")
+        _lib.check(L.gs_stream_fork(_wgrad_stream, side.cuda_stream), "gs_stream_fork")
         for d, x, dy, weight, gw, need, _ in jobs:
             ws_s = _side_workspace(need, dev, side)
             # dy and x must outlive the side-stream kernel that reads them: they are kept referenced
@@ -120,18 +126,30 @@ def join_side_streams(dev=None):
 
 
 def side_stream_after_main(dev):
-    """The side stream, made to wait for everything queued on the current (main) stream so far."""
+    """The side stream, made to wait for everything queued so far on the current stream and on the
+    other compute stream of this device (a gradient bucket holds BatchNorm gradients written on the
+    training stream and, where a branch ran, on the branch stream)."""
     s = _side_stream(dev)
+    key = (dev.type, dev.index)
     with torch.cuda.device(dev):
-        _lib.check(_L().gs_stream_fork(current_stream_ptr(), s.cuda_stream), "gs_stream_fork")
-    _side_dirty[(dev.type, dev.index)] = True   # the main stream joins it at the end of backward
+        cur = current_stream_ptr()
+        _lib.check(_L().gs_stream_fork(cur, s.cuda_stream), "gs_stream_fork")
+        others = set()
+        for bkey, br in _branch_streams.items():
+            if bkey[:2] == key and _branch_dirty.get(bkey):
+                others.add(br.cuda_stream)
+                others.add(_branch_origin.get(bkey))
+        for other in others:
+            if other is not None and other != cur:
+                _lib.check(_L().gs_stream_fork(other, s.cuda_stream), "gs_stream_fork")
+    _side_dirty[key] = True   # the main stream joins it at the end of backward
     return s
 
 
 def _side_workspace(need, dev, side):
     """Split-K scratch of the side stream (allocated under that stream, so the caching allocator
     orders its reuse against the side stream's kernels)."""
-    buf = _ws_side._buf.get((dev.type, dev.index))
+    buf = _ws_side._buf.get((dev.type, dev.index, 0))
     if buf is not None and buf.numel() >= need:
         return buf
     with torch.cuda.stream(side):
@@ -144,6 +162,215 @@ def reserve_workspaces(dev, nbytes=192 << 20):
     capture never sees a workspace being (re)allocated."""
     _ws.get(nbytes, dev)
     _side_workspace(nbytes, dev, _side_stream(dev))
+
+
+
+# ---- the branch stream -------------------------------------------------------------------------
+# A bs-2 step is ~450 launches of 5-100 us, each a single round of 1-4 workgroups per CU with its
+# ramp and its tail (DESIGN.md §12); the only thing that fills those is ANOTHER launch running beside
+# it.  Two sub-chains of the network are independent of the main chain and run on a second in-order
+# queue, fenced by events:
+#   * the projection shortcut (conv + BN) of a stage's first block, beside conv1 -> conv2, forward
+#     and backward (gaiaseg/models/utils/dynamic_res_layer.py:70-125);
+#   * the auxiliary head with its loss, beside stage 4 / the decode head
+#     ("dynamic_encoder_decoder-distill-backup (1).py":85-143: two independent consumers of x).
+# Same kernels, same operands, same results; only the queue differs.  GS_BRANCH=0 keeps one queue;
+# GS_BRANCH_SHORTCUT / GS_BRANCH_AUX switch the two uses separately.
+BRANCH = os.environ.get("GS_BRANCH", "1") != "0"
+BRANCH_SHORTCUT = BRANCH and os.environ.get("GS_BRANCH_SHORTCUT", "1") != "0"
+BRANCH_AUX = BRANCH and os.environ.get("GS_BRANCH_AUX", "1") != "0"
+SLOT_SHORTCUT, SLOT_AUX = 1, 2   # scratch slot / branch stream index (0 = the training stream)
+_branch_streams = {}     # (device type, index, slot) -> torch.cuda.Stream
+_branch_slot_of = {}     # raw stream handle -> slot (adopt_current_stream)
+_branch_origin = {}      # branch key -> raw handle of the stream it was last forked from
+_branch_dirty = {}
+_branch_cb_armed = False
+
+
+def _branch_stream(dev, slot):
+    key = (dev.type, dev.index, slot)
+    s = _branch_streams.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _branch_streams[key] = s
+        _branch_slot_of[s.cuda_stream] = slot
+    return s
+
+
+def on_branch():
+    return _ws.slot != 0
+
+
+def prefork_branch(dev, slot):
+    """Make branch stream ``slot`` wait for what is queued on the current stream NOW; a later
+    ``branch_scope(..., forked=True)`` then starts from this point of the current stream instead of
+    from its tail at that time (the auxiliary head forks behind stage 3 while the host goes on to
+    queue stage 4)."""
+    if not BRANCH or dev.type != "cuda" or on_branch():
+        return
+    br = _branch_stream(dev, slot)
+    key = (dev.type, dev.index, slot)
+    cur = current_stream_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(_L().gs_stream_fork(cur, br.cuda_stream), "gs_stream_fork")
+    _branch_origin[key] = cur
+    _branch_dirty[key] = True
+
+
+def _enter_branch(dev, slot, fork=True):
+    """Fork: branch stream ``slot`` waits for everything queued on the current stream, then becomes
+    the current stream (with its own scratch buffers).  Returns the stream to go back to."""
+    flush_wgrads()            # (backward) queued weight gradients belong to the stream we leave
+    br = _branch_stream(dev, slot)
+    prev = torch.cuda.current_stream(dev)
+    key = (dev.type, dev.index, slot)
+    if fork or _branch_origin.get(key) != prev.cuda_stream:
+        with torch.cuda.device(dev):
+            _lib.check(_L().gs_stream_fork(prev.cuda_stream, br.cuda_stream), "gs_stream_fork")
+        _branch_origin[key] = prev.cuda_stream
+    _branch_dirty[key] = True
+    torch.cuda.set_stream(br)
+    _ws.slot = slot
+    return prev
+
+
+def _leave_branch(prev):
+    flush_wgrads()
+    torch.cuda.set_stream(prev)
+    _ws.slot = 0
+
+
+def join_branch(dev, slot):
+    """The current stream waits for everything queued on branch stream ``slot`` so far."""
+    key = (dev.type, dev.index, slot)
+    br = _branch_streams.get(key)
+    if br is None or not _branch_dirty.get(key):
+        return
+    with torch.cuda.device(dev):
+        _lib.check(_L().gs_stream_fork(br.cuda_stream, current_stream_ptr()), "gs_stream_fork")
+
+
+def join_branch_streams():
+    """End of a step's backward: the stream the branches were forked from waits for them."""
+    global _branch_cb_armed
+    _branch_cb_armed = False
+    for key, br in _branch_streams.items():
+        if _branch_dirty.get(key) and _branch_origin.get(key) is not None:
+            with torch.cuda.device(br.device):
+                _lib.check(_L().gs_stream_fork(br.cuda_stream, _branch_origin[key]), "gs_stream_fork")
+            _branch_dirty[key] = False
+
+
+def adopt_current_stream():
+    """Entry of an autograd node's backward: autograd has made the node's forward stream current;
+    pick the matching scratch slot.  On a branch stream also arrange for the final join (nothing
+    else would order a later reader on the training stream behind, e.g., the auxiliary head's
+    BatchNorm gradients when no upstream node consumes a gradient of this one)."""
+    global _branch_cb_armed
+    prev = _ws.slot
+    if _branch_slot_of:
+        slot = _branch_slot_of.get(current_stream_ptr(), 0)
+        if slot != prev:
+            flush_wgrads()
+        _ws.slot = slot
+        if slot and not _branch_cb_armed:
+            _branch_cb_armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(join_branch_streams)
+    return prev
+
+
+def restore_stream_slot(prev):
+    if _ws.slot != prev:
+        flush_wgrads()
+        _ws.slot = prev
+
+
+class branch_scope:
+    """``with ops.branch_scope(dev):`` evaluate a whole sub-model (the auxiliary head and its loss)
+    on a branch stream.  Its autograd nodes run their backward there too (autograd's stream
+    semantics); ``ops.join_branch(dev, slot)`` afterwards orders the current stream behind it.
+    ``forked``: the branch already waits for the right point of the current stream
+    (``prefork_branch``)."""
+
+    def __init__(self, dev, enabled=True, slot=SLOT_AUX, forked=False):
+        self.dev, self.slot, self.forked = dev, slot, forked
+        self.on = bool(enabled and BRANCH and dev.type == "cuda" and not on_branch())
+        self.prev = None
+
+    def __enter__(self):
+        if self.on:
+            self.prev = _enter_branch(self.dev, self.slot, fork=not self.forked)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _leave_branch(self.prev)
+        return False
+
+
+class Branch:
+    """A sub-chain of ONE tape evaluated on a branch stream.
+
+        br = Branch(tape, dev)
+        with br:                          # forward: fork; ops run (and record) on the branch
+            identity = shortcut(x)
+        a = conv1(x)
+        br.record_backward_join(tape)     # backward: everything recorded BEFORE this point runs
+                                          #           after the branch's backward has finished
+        b = conv2(a)
+        br.record_backward_body(tape)     # backward: fork here, replay the branch's closures
+        br.join()                         # forward: the current stream waits for the branch
+        out = conv3(b) + identity
+
+    Backward order on the host: conv3, [fork, branch body], conv2, [join], conv1 — the branch's data
+    gradient is the FIRST writer of x.g, conv1's accumulates onto it after the join.  With the
+    branch switched off the same closures run in the same order on one stream."""
+
+    __slots__ = ("tape", "dev", "on", "ops", "slot", "_saved", "_prev")
+
+    def __init__(self, tape, dev, enabled=True, slot=SLOT_SHORTCUT):
+        self.tape, self.dev, self.slot = tape, dev, slot
+        self.on = bool(enabled and BRANCH and dev.type == "cuda" and not on_branch())
+        self.ops = []
+        self._saved = self._prev = None
+
+    def __enter__(self):
+        self._saved = self.tape.ops
+        self.tape.ops = self.ops
+        if self.on:
+            self._prev = _enter_branch(self.dev, self.slot)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _leave_branch(self._prev)
+        self.tape.ops = self._saved
+        self._saved = self._prev = None
+        return False
+
+    def join(self):
+        if self.on:
+            join_branch(self.dev, self.slot)
+
+    def record_backward_join(self, tape):
+        if not self.on:
+            return
+        dev, slot = self.dev, self.slot
+        tape.record(lambda: join_branch(dev, slot))
+
+    def record_backward_body(self, tape):
+        body, dev, on, slot = self.ops, self.dev, self.on, self.slot
+
+        def backward():
+            prev = _enter_branch(dev, slot) if on else None
+            try:
+                for fn in reversed(body):
+                    fn()
+            finally:
+                if on:
+                    _leave_branch(prev)
+        if body:
+            tape.record(backward)
 
 
 def _L():
@@ -276,6 +503,8 @@ def _trace_relu_deferred(bn, y, coeffs):
 _defer = os.environ.get("GS_DEFER_BN", "conv3").lower()
 DEFER_EDGES = {"all": {"conv2", "conv3"}, "none": set()}.get(_defer, set(_defer.split(",")))
 DEFER_BN = True   # master switch (tests flip it to compare the two forms bit for bit)
+# the projection shortcut's BatchNorm inside the block's last apply pass (gs_bn_args.residual_coeffs)
+DEFER_SHORTCUT_BN = os.environ.get("GS_DEFER_SHORTCUT_BN", "1") != "0"
 
 
 def materialize(tape, x):
@@ -287,6 +516,19 @@ def materialize(tape, x):
                                 current_stream_ptr()), "gs_bn_apply")
     z.requires_grad = x.requires_grad
     add_grad_passthrough(tape, x, z)
+    return z
+
+
+def materialize_residual(tape, r):
+    """Write out bn(t) of a residual whose BatchNorm was left to its consumer (Act.res_affine), for
+    consumers that take a plain addend."""
+    if r is None or r.res_affine is None:
+        return r
+    z = Act.empty(r.N, r.H, r.W, r.C, r.t.device)
+    _lib.check(_L().gs_bn_apply(r.ptr, r.rows, r.C, r.ld, r.res_affine.data_ptr(), None, 0, 0, z.ptr,
+                                z.ld, current_stream_ptr()), "gs_bn_apply")
+    z.requires_grad = r.requires_grad
+    add_grad_passthrough(tape, r, z)
     return z
 
 
@@ -435,6 +677,7 @@ def batchnorm(tape, x, bn, relu=False, residual=None, out=None, inplace=False):
     storage for y (only when x is not needed by backward, i.e. never in training)."""
     L = _L()
     x = materialize(tape, x)
+    residual = materialize_residual(tape, residual)
     dev = x.t.device
     C, rows = x.C, x.rows
     st = current_stream_ptr()
@@ -594,7 +837,7 @@ def _bn_pointers(args, bn):
 
 
 def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
-            tag=None, defer=False, owns_input_grad=False):
+            tag=None, defer=False, owns_input_grad=False, defer_residual=False):
     """z = act(BN(conv(x, weight[:co, :x.C])) (+ residual)) through ONE library call per direction
     (gs_conv_bn_forward / gs_conv_bn_backward): same kernels, same results as conv2d() followed by
     batchnorm(), a third of the host work.  Rank-local BatchNorm only (``bn.process_group`` None);
@@ -604,6 +847,11 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
     activation carries the coefficients (Act.affine) and its consumer — the next conv_bn — evaluates
     relu(bn(y)) in its operand loaders, forward and weight gradient (gs_conv_desc.in_affine).  A
     deferred INPUT ``x`` is consumed that way when the library supports the shape, else written out.
+
+    ``defer_residual`` (no relu, no residual, no ``out``): likewise the BN is not applied; the returned
+    activation (the raw conv output) carries the coefficients in ``Act.res_affine`` and must be used
+    as the ``residual`` of a conv_bn call, whose apply pass adds bn(residual)
+    (gs_bn_args.residual_coeffs).  A ``residual`` that carries ``res_affine`` is consumed that way.
 
     ``owns_input_grad``: this conv's data gradient is the LAST contribution to ``x.g`` (accumulation
     included).  If x came out of a training-mode BN + ReLU (``x.bnb``), the dgrad epilogue then also
@@ -615,6 +863,7 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
         raise ValueError("conv_bn needs an output width that is a multiple of 4, got %d" % co)
     dev = x.t.device
     defer = bool(defer and DEFER_BN and relu and residual is None and out is None)
+    defer_residual = bool(defer_residual and DEFER_BN and not relu and residual is None and out is None)
     use_batch = bn.training or bn.running_mean is None
     plans = weight.__dict__.get("_gs_plans")
     if plans is None:
@@ -640,11 +889,13 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
     y = Act.empty(pl.n, pl.ho, pl.wo, co, dev)
     in_affine = x.affine   # kept alive by the backward closure
     d.in_affine = in_affine.data_ptr() if in_affine is not None else None
-    if defer:
+    if defer or defer_residual:
         out = y
     elif out is None:
         out = Act.empty(pl.n, pl.ho, pl.wo, co, dev)
     _bn_pointers(args, bn)
+    res_affine = residual.res_affine if residual is not None else None   # (kept alive by the closure)
+    args.residual_coeffs = res_affine.data_ptr() if res_affine is not None else None
     # A block output relu(bn(y) + identity) whose consumer may fold this BatchNorm's backward
     # reduction into its data-gradient epilogue: the apply pass also writes the ReLU mask as one byte
     # per channel quad, so that epilogue reads rows * C / 4 bytes instead of the activation again
@@ -660,14 +911,16 @@ def conv_bn(tape, x, weight, co, bn, stride=1, pad=0, dil=1, relu=False, residua
     _lib.check(L.gs_conv_bn_forward(ctypes.byref(d), x.ptr, weight.data_ptr(), ctypes.byref(args),
                                     residual.ptr if residual is not None else None,
                                     residual.ld if residual is not None else 0, y.ptr,
-                                    coeffs.data_ptr(), None if defer else out.ptr, out.ld,
-                                    ws.data_ptr(), ws.numel(), current_stream_ptr()),
+                                    coeffs.data_ptr(), None if (defer or defer_residual) else out.ptr,
+                                    out.ld, ws.data_ptr(), ws.numel(), current_stream_ptr()),
                "gs_conv_bn_forward")
     if use_batch and bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked()
     if defer:
         out.affine = coeffs
         _trace_relu_deferred(bn, y, coeffs)
+    elif defer_residual:
+        out.res_affine = coeffs
     elif relu:
         _trace_relu(bn, out)
     if relu and use_batch and BNBWD_FUSE and tape.enabled and out.parent is None:

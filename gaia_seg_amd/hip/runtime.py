@@ -37,17 +37,20 @@ def require_gpu_tensor(t, what):
 
 
 class _Workspace:
-    """Grow-only scratch buffer per device (split-K slabs, reduction partials).
+    """Grow-only scratch buffer per device and stream slot (split-K slabs, reduction partials).
 
-    All kernels of a step run in order on one stream, so a single shared buffer is safe."""
+    All kernels of one in-order queue share a buffer.  ``slot`` selects the queue: 0 = the training
+    stream, 1 = the branch stream (hip/ops.py: projection shortcuts, the auxiliary head); whoever
+    switches the current stream switches the slot with it."""
 
     def __init__(self):
         self._buf = {}
         self._retired = []   # outgrown buffers: captured step graphs may still point into them
+        self.slot = 0
 
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 256)
-        key = (device.type, device.index)
+        key = (device.type, device.index, self.slot)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             # round up generously so later, larger requests rarely reallocate
@@ -77,7 +80,7 @@ class Act:
     ``nchw_image`` marks the network input, which is read in place through NCHW strides."""
 
     __slots__ = ("t", "_g", "requires_grad", "parent", "c0", "nchw_image",
-                 "N", "H", "W", "C", "ld", "rows", "ptr", "affine", "bnb", "bnb_sums")
+                 "N", "H", "W", "C", "ld", "rows", "ptr", "affine", "bnb", "bnb_sums", "res_affine")
 
     def __init__(self, t, requires_grad=True, parent=None, c0=0, nchw_image=False):
         self.t = t
@@ -91,6 +94,10 @@ class Act:
         # consumer convolution applies it in its operand loader (gs_conv_desc.in_affine) or
         # ops.materialize() writes it out.  ``g`` is always the gradient of the logical value.
         self.affine = None
+        # Deferred BatchNorm WITHOUT activation (the projection shortcut): when set (a coefficient
+        # tensor), the logical value is bn(t); its only consumer, the residual add of the block's last
+        # BatchNorm, applies it (gs_bn_args.residual_coeffs).
+        self.res_affine = None
         # Cross-layer fusion of the BatchNorm backward reduction (ops.conv_bn): ``bnb`` = (y Act,
         # coefficient tensor, mask mode) describes the BN + ReLU that
         # produced this activation; a consumer whose data gradient is the last contribution to ``g``
@@ -255,6 +262,17 @@ class _TapeFunction(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, *grads):
+        # autograd runs a node's backward on the stream its forward ran on: a head evaluated on the
+        # branch stream (ops.branch_scope) comes back here with that stream current
+        from . import ops as _ops
+        prev_slot = _ops.adopt_current_stream()
+        try:
+            return _TapeFunction._backward_on_stream(ctx, *grads)
+        finally:
+            _ops.restore_stream_slot(prev_slot)
+
+    @staticmethod
+    def _backward_on_stream(ctx, *grads):
         for o, g in zip(ctx.outs, grads):
             if g is not None:
                 o.set_grad_from_nchw(g)

@@ -117,12 +117,16 @@ class DynamicResNet(nn.Module, DynamicMixin):
                 if count > len(layer):
                     raise ValueError("frozen_layers asks for %d blocks of %s, which has %d"
                                      % (count, name, len(layer)))
-                mods += list(layer[:count])
+                mods += list(layer)[:count]   # (ModuleList slicing would re-run the constructor)
         return mods
 
     def _freeze_stages(self):
         for m in self._frozen_modules():
             freeze(m)
+        if self.frozen_stages >= 0 and not self.deep_stem:
+            # the reference puts only norm1 into eval mode here (dynamic_resnet.py:311-315); a conv has
+            # no mode-dependent behaviour, the flag is mirrored so module.training reads the same
+            self.conv1.training = self.training
 
     _freeze_layers = _freeze_stages   # one pass covers both options (kept for API parity)
 
@@ -182,8 +186,15 @@ class DynamicResNet(nn.Module, DynamicMixin):
         mp = self.maxpool
         x = ops.maxpool(tape, x, mp.kernel_size, mp.stride, mp.padding)
         outs = []
+        fork_stage = self.__dict__.get("aux_fork_stage")   # set by the segmentor (auxiliary heads)
+        self.__dict__["_aux_forked"] = False
+        last = len(self.res_layers) - 1
         for i, layer_name in enumerate(self.res_layers):
             x = getattr(self, layer_name).forward_act(tape, x)
+            if i == fork_stage and i < last and tape.enabled and ops.BRANCH_AUX:
+                # the auxiliary heads' inputs are complete: their branch stream starts from here
+                ops.prefork_branch(x.t.device, ops.SLOT_AUX)
+                self.__dict__["_aux_forked"] = True
             if i == 0:
                 # backward crosses this point last-but-one: parameters of every later layer can be
                 # updated while the side stream finishes the stem / stage-1 weight gradients

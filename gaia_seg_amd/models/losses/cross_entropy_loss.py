@@ -73,6 +73,15 @@ class _FusedResizeCE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss, grad_acc):
+        from ...hip import ops as _ops
+        prev_slot = _ops.adopt_current_stream()   # (the auxiliary head's loss runs on the branch stream)
+        try:
+            return _FusedResizeCE._backward(ctx, grad_loss)
+        finally:
+            _ops.restore_stream_slot(prev_slot)
+
+    @staticmethod
+    def _backward(ctx, grad_loss):
         logits, label, lse = ctx.saved_tensors
         L = _lib.load()
         d = ctx.desc

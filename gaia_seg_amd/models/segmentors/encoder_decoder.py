@@ -62,6 +62,22 @@ class EncoderDecoder(nn.Module):
                     [builder.build_head(h) for h in auxiliary_head])
             else:
                 self.auxiliary_head = builder.build_head(auxiliary_head)
+            self._plan_aux_fork()
+
+    def _plan_aux_fork(self):
+        """Tell the backbone behind which stage the auxiliary heads have all their inputs: the
+        branch stream they run on forks from the training stream there (ops.prefork_branch), so
+        they overlap the later stages as well as the decode head."""
+        heads = (list(self.auxiliary_head) if isinstance(self.auxiliary_head, nn.ModuleList)
+                 else [self.auxiliary_head])
+        out_indices = getattr(self.backbone, "out_indices", None)
+        if out_indices is None or self.with_neck:
+            return
+        used = set()
+        for h in heads:
+            idx = h.in_index if isinstance(h.in_index, (list, tuple)) else [h.in_index]
+            used.update(i % len(out_indices) for i in idx)
+        self.backbone.aux_fork_stage = out_indices[max(used)]
 
     def init_weights(self, pretrained=None):
         self.backbone.init_weights(pretrained=pretrained)
@@ -130,9 +146,25 @@ class EncoderDecoder(nn.Module):
     def forward_train(self, img, img_metas, gt_semantic_seg):
         x = self.extract_feat(img)
         losses = dict()
+        if not self.with_auxiliary_head:
+            losses.update(self._decode_head_forward_train(x, img_metas, gt_semantic_seg))
+            return losses
+        # The decode head and the auxiliary head(s) are independent consumers of x
+        # ("dynamic_encoder_decoder-distill-backup (1).py":85-143; same call order here): the
+        # auxiliary heads and their losses are queued on a branch stream (forward here, backward by
+        # autograd's stream semantics) that forked from the training stream where their inputs were
+        # complete — behind the backbone stage they read, or here at the latest — so they run beside
+        # the rest of the backbone and the decode head.
+        dev = img.device
+        branch = ops.BRANCH_AUX and dev.type == "cuda"
+        if branch and not getattr(getattr(self, "backbone", None), "_aux_forked", False):
+            ops.prefork_branch(dev, ops.SLOT_AUX)
         losses.update(self._decode_head_forward_train(x, img_metas, gt_semantic_seg))
-        if self.with_auxiliary_head:
-            losses.update(self._auxiliary_head_forward_train(x, img_metas, gt_semantic_seg))
+        with ops.branch_scope(dev, branch, forked=True):
+            loss_aux = self._auxiliary_head_forward_train(x, img_metas, gt_semantic_seg)
+        if branch:
+            ops.join_branch(dev, ops.SLOT_AUX)     # whoever sums the losses reads both
+        losses.update(loss_aux)
         return losses
 
     # ---- test time: one fused epilogue kernel per view (core/inference.py, csrc/inference.hip) ----

@@ -207,6 +207,13 @@ typedef struct gs_bn_args {
                                 writes the ReLU mask [rows][Co/4], one byte per channel quad
                                 (bit e set <=> z[.., 4q+e] > 0) -- 1/16 of z, for the consumer's
                                 fused BatchNorm-backward epilogue (gs_bn_bwd_fuse mode 3)          */
+  const float* residual_coeffs; /* forward, residual != NULL: if not NULL, `residual` is the RAW
+                                output of another conv (the projection shortcut of a stage's first
+                                block, gaiaseg/models/utils/dynamic_res_layer.py:70-94) and these
+                                are that conv's BatchNorm coefficients [scale | beta | mean | ..][C]
+                                (layout of `coeffs`): the apply pass adds
+                                (residual - mean) * scale + beta, so the shortcut's normalised
+                                output is never written or read                                     */
 } gs_bn_args;
 /* max(gs_conv2d_workspace_bytes, gs_bn_stats_workspace_bytes) for this conv's output */
 size_t gs_conv_bn_workspace_bytes(const gs_conv_desc* d);

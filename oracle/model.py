@@ -86,11 +86,12 @@ class OBottleneck(nn.Module):
     """DynamicBottleneck (A3), style='pytorch': stride on the 3x3."""
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style="pytorch"):
         super().__init__()
-        self.conv1 = OConv(inplanes, planes, 1, bias=False)
+        s1, s2 = (1, stride) if style == "pytorch" else (stride, 1)   # 'caffe': stride on the first 1x1
+        self.conv1 = OConv(inplanes, planes, 1, stride=s1, bias=False)
         self.bn1 = OBN(planes)
-        self.conv2 = OConv(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation,
+        self.conv2 = OConv(planes, planes, 3, stride=s2, padding=dilation, dilation=dilation,
                            bias=False)
         self.bn2 = OBN(planes)
         self.conv3 = OConv(planes, planes * 4, 1, bias=False)
@@ -118,7 +119,7 @@ class OBottleneck(nn.Module):
 
 class OResLayer(nn.ModuleList):
     def __init__(self, inplanes, planes, depth, stride=1, dilation=1, contract_dilation=False,
-                 avg_down=False):
+                 avg_down=False, style="pytorch"):
         downsample = None
         if stride != 1 or inplanes != planes * 4:  # dynamic_res_layer.py:70-94
             mods, conv_stride = [], stride
@@ -129,9 +130,9 @@ class OResLayer(nn.ModuleList):
             mods += [OConv(inplanes, planes * 4, 1, stride=conv_stride, bias=False), OBN(planes * 4)]
             downsample = nn.Sequential(*mods)
         first_dilation = dilation // 2 if (dilation > 1 and contract_dilation) else dilation
-        layers = [OBottleneck(inplanes, planes, stride, first_dilation, downsample)]
+        layers = [OBottleneck(inplanes, planes, stride, first_dilation, downsample, style)]
         for _ in range(1, depth):
-            layers.append(OBottleneck(planes * 4, planes, 1, dilation))
+            layers.append(OBottleneck(planes * 4, planes, 1, dilation, style=style))
         super().__init__(layers)
         self.depth_state = depth
 
@@ -144,8 +145,9 @@ class OResLayer(nn.ModuleList):
 class ODynamicResNet(nn.Module):
     def __init__(self, in_channels, stem_width, body_width, body_depth, strides=(1, 2, 2, 2),
                  dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), deep_stem=False,
-                 contract_dilation=False, avg_down=False, **unused):
+                 contract_dilation=False, avg_down=False, num_stages=4, style="pytorch", **unused):
         super().__init__()
+        body_depth = body_depth[:num_stages]   # dynamic_resnet.py:134
         self.deep_stem = deep_stem
         self.out_indices = out_indices
         if deep_stem:  # dynamic_resnet.py:258-288
@@ -164,7 +166,7 @@ class ODynamicResNet(nn.Module):
         self.res_layers = []
         for i, depth in enumerate(body_depth):
             layer = OResLayer(inplanes, body_width[i], depth, strides[i], dilations[i],
-                              contract_dilation, avg_down)
+                              contract_dilation, avg_down, style)
             inplanes = body_width[i] * 4
             name = "layer%d" % (i + 1)
             self.add_module(name, layer)
@@ -232,9 +234,12 @@ class _OHeadBase(nn.Module):
 class OFCNHead(_OHeadBase):
     def __init__(self, in_channels, channels, num_classes, num_convs=2, kernel_size=3,
                  concat_input=True, dropout_ratio=0.1, in_index=-1, loss_weight=1.0,
-                 ignore_index=255, align_corners=False, **unused):
+                 ignore_index=255, align_corners=False, input_transform=None, **unused):
         super().__init__(channels, num_classes, in_index, dropout_ratio, loss_weight, ignore_index,
                          align_corners)
+        self.input_transform = input_transform
+        if input_transform == "resize_concat":     # fcn_head.py:139-173
+            in_channels = sum(in_channels)
         convs = [OConvModule(in_channels if i == 0 else channels, channels, kernel_size,
                              padding=kernel_size // 2) for i in range(num_convs)]
         self.convs = nn.Identity() if num_convs == 0 else nn.Sequential(*convs)
@@ -244,7 +249,12 @@ class OFCNHead(_OHeadBase):
                                         padding=kernel_size // 2)
 
     def forward(self, inputs):  # dynamic_fcn_head.py:128-135
-        x = inputs[self.in_index]
+        if self.input_transform == "resize_concat":   # fcn_head.py:187-195
+            sel = [inputs[i] for i in self.in_index]
+            x = torch.cat([O.resize(t, size=sel[0].shape[2:], mode="bilinear",
+                                    align_corners=self.align_corners) for t in sel], dim=1)
+        else:
+            x = inputs[self.in_index]
         output = self.convs(x)
         if self.concat_input:
             output = self.conv_cat(torch.cat([x, output], dim=1))

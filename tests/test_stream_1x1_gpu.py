@@ -118,6 +118,40 @@ def test_stream_kernel_matches_conv2d(hip_lib, case):
             assert torch.equal(got[..., ci:], prior[..., ci:])
 
 
+def test_padded_1x1_data_gradient_keeps_the_tile_kernel(hip_lib):
+    """A 1x1 conv with pad = 1 has Ho = H + 2: the streaming kernel maps dy row m to dx row m and must
+    not take it (r03 advisor finding: the dispatch checked stride and kernel size only).  The launch
+    record and gs_debug_query_conv_launch agree, and the values match F.conv2d's gradient."""
+    from gaia_seg_amd.hip import lib
+    from gaia_seg_amd.hip.runtime import current_stream_ptr
+    n, h, w, ci, co = 2, 126, 254, 64, 64
+    ho, wo = h + 2, w + 2
+    torch.manual_seed(5)
+    w_log = torch.randn(co, ci, 1, 1) * 0.2
+    w_phys = w_log.permute(2, 3, 1, 0).contiguous().to(DEV)
+    d = lib.ConvDesc(N=n, H=h, W=w, Ci=ci, Co=co, Ci_max=ci, Co_ld=co, KH=1, KW=1, stride=1, pad=1,
+                     dil=1, Ho=ho, Wo=wo, x_sn=h * w * ci, x_sh=w * ci, x_sw=ci, x_sc=1, ldy=co,
+                     ld_add=0, role=0, reserved=0, in_affine=None)
+    q = lib.DebugLaunch()
+    assert hip_lib.gs_debug_query_conv_launch(ctypes.byref(d), lib.OP_DGRAD, ctypes.byref(q)) == 0
+    assert q.kloop != lib.KLOOP_STREAM
+    need = hip_lib.gs_conv2d_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=DEV)
+    dy = torch.randn(n, ho, wo, co)
+    x0 = torch.zeros(n, ci, h, w, requires_grad=True)
+    F.conv2d(x0, w_log, padding=1).backward(dy.permute(0, 3, 1, 2))
+    dx_ref = x0.grad.permute(0, 2, 3, 1)
+    dx = torch.full((n, h, w, ci), float("nan"), device=DEV)
+    lib.check(hip_lib.gs_conv2d_dgrad(ctypes.byref(d), dy.to(DEV).data_ptr(), w_phys.data_ptr(),
+                                      dx.data_ptr(), 0, ws.data_ptr(), need, current_stream_ptr()),
+              "dgrad")
+    torch.cuda.synchronize()
+    rec = lib.DebugLaunch()
+    assert hip_lib.gs_debug_last_conv_launch(ctypes.byref(rec)) == 0 and rec.op == lib.OP_DGRAD
+    assert rec.kloop != lib.KLOOP_STREAM and rec.kloop == q.kloop
+    assert rel_err(dx.cpu(), dx_ref) < TOL
+
+
 def _stream_counts(hip_lib):
     from gaia_seg_amd.hip import lib
     counts = (ctypes.c_int64 * (3 * lib.KLOOP_COUNT * 3))()
