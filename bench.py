@@ -72,6 +72,11 @@ def parse_args():
                     help="replay recurring subnets' training step from a captured HIP graph "
                          "(IterBasedRunner.train_iter; off by default: slower on ROCm 7.2, see "
                          "DESIGN.md); diagnostics / A-B only")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="no GPU work: print the data-parallel exchange plan of --gpus N ranks (gradient "
+                         "buckets, bytes and collective launches per step for MIN / R50 / MAX and the "
+                         "seeded --steps-draw mix, SyncBN collectives per step, expected all-reduce time "
+                         "at a stated bus bandwidth) as one JSON object and exit")
     ap.add_argument("--crop", default=None,
                     help="HxW override of the crop size (diagnostics only, e.g. 64x128 makes the GPU "
                          "work negligible and exposes the host cost per step; the headline "
@@ -301,8 +306,73 @@ def step_flops(model, sampler, seed, steps, size, bs, fixed_meta):
     return total, k3
 
 
+# Ring all-reduce over xGMI: every GPU has 7 links x ~153 GB/s (one per peer); a ring uses one link per
+# direction and hop, RCCL runs several rings / a tree over the mesh.  The figure below is the ASSUMED
+# large-message bus bandwidth the plan prices the exchange with (RCCL all-reduce, 8 GPUs, >= 64 MB
+# messages); replace it with the measured one once a node is available.
+PLAN_BUS_GBPS = 300.0
+
+
+def plan_only(args):
+    """--plan-only: what the data-parallel exchange of one step looks like at --gpus N, from host
+    arithmetic alone (the bucket planner of core/dist.py over the arena layout)."""
+    import torch
+    from gaia_seg_amd.core.config import Config
+    from gaia_seg_amd.core.dist import GradReducer
+    from gaia_seg_amd.core.dynamic import fold_dict
+    from gaia_seg_amd.core.model_space import build_model_sampler
+    from gaia_seg_amd.core.param_arena import _ALIGN, arena_layout
+    from gaia_seg_amd.core.bricks import DynamicBatchNorm2d
+    from gaia_seg_amd.hip.runtime import round_up
+    from gaia_seg_amd.models import build_segmentor
+    cfg = Config.fromfile(args.config)
+    torch.manual_seed(args.seed)
+    model = build_segmentor(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg")).train()
+    layout, total = arena_layout(model)
+    segments = {id(p_): (o, round_up(max(n, 1), _ALIGN)) for _, p_, _, o, n in layout}
+    reducer = GradReducer(torch.zeros(1), segments)      # planner only: nothing is reduced
+    n = max(args.gpus, 1)
+    sampler = build_model_sampler(cfg.train_sampler)
+    anchors = {a["name"]: dict(a) for a in sampler.model_samplers[0].anchors}
+
+    def one(meta):
+        model.manipulate_arch(fold_dict(meta)["arch"])
+        params = [p_ for p_ in model.active_parameters() if p_.requires_grad]
+        plan = reducer._plan(params, None)
+        runs = [r for b in plan for r in b["runs"]]
+        nbytes = 4 * sum(b_ - a_ for a_, b_ in runs)
+        payload = 4 * sum(segments[id(p_)][1] for p_ in params)
+        sync = [m for m in model.modules() if isinstance(m, DynamicBatchNorm2d) and m.sync is not None]
+        t_ms = 2.0 * (n - 1) / n * nbytes / (PLAN_BUS_GBPS * 1e9) * 1e3 if n > 1 else 0.0
+        return dict(buckets=len(plan), collective_launches=len(plan),
+                    runs=len(runs), allreduce_bytes=nbytes, active_parameter_bytes=payload,
+                    padded_hole_bytes=nbytes - payload,
+                    bucket_bytes=[4 * sum(b_ - a_ for a_, b_ in b["runs"]) for b in plan],
+                    syncbn_layers=len(sync), syncbn_collectives=2 * len(sync),
+                    expected_allreduce_ms=round(t_ms, 3))
+    out = {"plan_only": True, "n_gpus": n, "config": os.path.basename(args.config),
+           "arena_bytes": 4 * total, "bucket_cap_bytes": 4 * reducer.bucket_elems,
+           "assumed_bus_bandwidth_GBps": PLAN_BUS_GBPS,
+           "expected_allreduce_ms_is": "2 (N-1)/N x bytes / bus bandwidth: ring all-reduce at the assumed "
+                                       "large-message bus bandwidth; buckets are issued during backward on "
+                                       "the weight-gradient stream, so all but the last bucket overlap it",
+           "per_step": {}}
+    for name in ("MIN", "R50", "MAX"):
+        if name in anchors:
+            out["per_step"][name] = one(anchors[name])
+    sampler.seed(args.seed)
+    mix = [one(sampler.sample()) for _ in range(args.steps)]
+    keys = ("buckets", "collective_launches", "allreduce_bytes", "active_parameter_bytes",
+            "syncbn_collectives", "expected_allreduce_ms")
+    out["per_step"]["mix_of_%d_draws_mean" % args.steps] = {
+        k: round(sum(m[k] for m in mix) / len(mix), 3) for k in keys}
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
+    if args.plan_only:
+        return plan_only(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)   # never returns
     import torch
@@ -460,7 +530,14 @@ def main():
     import ctypes
     L.gs_debug_conv_launch_flops(None, 1)
     L.gs_debug_k3_flops(None, 1)
+    if runner.step_events is not None:
+        runner.step_events.clear()
     passes = [timed_pass(False)]                     # <- `value`: nothing but the training steps
+    if runner.step_events is not None:
+        print("step events (mean ms from step begin, first pass): "
+              + ", ".join("%s %.3f" % kv for kv in sorted(runner.step_event_summary().items(),
+                                                          key=lambda kv: kv[1])), file=sys.stderr)
+        runner.step_events = None
     kl = (ctypes.c_double * 15)()
     L.gs_debug_conv_launch_flops(kl, 1)              # which MFMA path carried the first pass's FLOPs
     k3kl = (ctypes.c_double * 5)()
@@ -549,6 +626,15 @@ def main():
                                          "start-up, warm-up and the timed steps"),
             },
             "check": check,
+            "distributed": {
+                "backend": (dist.get_backend() if world > 1 else None),
+                "world_size": (dist.get_world_size() if world > 1 else 1),
+                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())
+                if hasattr(torch.cuda, "nccl") else None,
+                "collectives_per_step": round(collectives_per_step, 1),
+                "allreduce_bytes_per_step_per_rank": int(bytes_per_step),
+                "early_optimizer_steps": runner.early_steps,
+            },
         }
         hooks = [h for h in runner.hooks if isinstance(h, ManipulateArchHook)]
         if hooks:

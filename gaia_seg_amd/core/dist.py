@@ -267,6 +267,22 @@ class GradReducer:
                                                async_op=True))
             self.collectives += 1
 
+    def wait_launched(self):
+        """Make the CURRENT stream wait for every bucket launched so far and return their arena runs
+        (None on one rank: nothing is exchanged, every gradient is final as written).  Used by the
+        early optimizer instalment, which may only touch what has been reduced."""
+        st = self._active
+        if st is None:
+            return None
+        for w in self._works:
+            w.wait()
+        self._works = []
+        runs = []
+        for bi, launched in enumerate(st["launched"]):
+            if launched:
+                runs.extend(st["plan"][bi]["runs"])
+        return runs
+
     def finish(self):
         """Flush buckets whose parameters never reported (no gradient this step) and wait."""
         st = self._active

@@ -21,6 +21,21 @@ from .bricks import hwio_logical_view
 _ALIGN = 64  # floats: 256-byte aligned segments (float4 loads need 16 B; keep cache lines whole)
 
 
+def arena_layout(model):
+    """[(name, parameter, physical shape or None, offset, physical numel)], total elements: where every
+    parameter sits in the flat arenas (forward order, 256-byte aligned segments).  Host arithmetic
+    only — `bench.py --plan-only` sizes the gradient buckets from it without a GPU."""
+    off, layout = 0, []
+    for name, p in model.named_parameters():
+        phys = getattr(p, "_gs_phys_shape", None)
+        n_phys = 1
+        for s in (phys if phys is not None else p.shape):
+            n_phys *= s
+        layout.append((name, p, phys, off, n_phys))
+        off += round_up(max(n_phys, 1), _ALIGN)
+    return layout, off
+
+
 class ParamArena:
     def __init__(self, model):
         from .bricks import DynamicConv2d, relayout_conv_params
@@ -36,15 +51,7 @@ class ParamArena:
         self.device = dev
         self.segments = {}   # id(param) -> (offset, numel_phys)
         self.names = {}
-        off = 0
-        layout = []
-        for name, p in params:
-            phys = getattr(p, "_gs_phys_shape", None)
-            n_phys = 1
-            for s in (phys if phys is not None else p.shape):
-                n_phys *= s
-            layout.append((name, p, phys, off, n_phys))
-            off += round_up(max(n_phys, 1), _ALIGN)
+        layout, off = arena_layout(model)
         self.numel = off
         self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)

@@ -75,14 +75,66 @@ class FixedLrUpdaterHook(Hook):
         runner.lr = runner.base_lr
 
 
+def _ranges_subtract(a, b):
+    """a minus b for sorted lists of disjoint [begin, end) ranges."""
+    out, j = [], 0
+    for lo, hi in a:
+        cur = lo
+        while j < len(b) and b[j][1] <= cur:
+            j += 1
+        k = j
+        while k < len(b) and b[k][0] < hi:
+            if b[k][0] > cur:
+                out.append((cur, b[k][0]))
+            cur = max(cur, b[k][1])
+            k += 1
+        if cur < hi:
+            out.append((cur, hi))
+    return out
+
+
+def _ranges_intersect(a, b):
+    return _ranges_subtract(a, _ranges_subtract(a, b))
+
+
 class ArenaOptimizerHook(Hook):
-    """OptimizerHook for the flat-arena SGD: the step touches only the active subnet's ranges."""
+    """OptimizerHook for the flat-arena SGD: the step touches only the active subnet's ranges.
+
+    Three instalments, each as early as its gradients are final:
+      * stages 3.. of the backbone and the heads (~95 % of the parameters) on the optimizer stream, in
+        the MIDDLE of backward — when the replay crosses the backbone's "stage2|stage3" mark.
+        Opt-in (GS_EARLY_SGD=1): measured neutral — the end of the step is set by the total work of
+        backward, not by where the optimizer's HBM traffic sits (profiles/r04_stream_experiments.md);
+        without it these ranges are updated with stage 2's;
+      * stage 2 once the weight-gradient stream has passed the checkpoint behind stage 1;
+      * the stem and stage 1 after the weight-gradient stream has drained."""
 
     in_graph = True   # backward + SGD are part of a captured step graph (IterBasedRunner)
+    EARLY = os.environ.get("GS_EARLY_SGD", "0") == "1"   # measured neutral (profiles/r04_stream_experiments.md): opt-in
 
     def __init__(self, grad_clip=None):
         if grad_clip is not None:
             raise NotImplementedError("grad_clip is not configured by the in-tree configs")
+
+    def _early_step(self, runner, tag, done):
+        """Backward has crossed ``tag``: update what is final, on the optimizer stream."""
+        from ..hip import ops
+        if tag != "stage2|stage3" or done:
+            return
+        ranges = runner.early_ranges()
+        if not ranges:
+            return
+        dev = runner.arena.device
+        opt = ops.opt_stream(dev)
+        ops.fork_to(opt, dev)          # weight gradients (side stream), BN gradients (this stream, branches)
+        with torch.cuda.stream(opt):
+            covered = runner.reducer.wait_launched()   # multi-GPU: what has been all-reduced so far
+            if covered is not None:
+                ranges = _ranges_intersect(ranges, sorted(covered))
+            if ranges:
+                runner.arena.sgd_step(ranges, runner.lr, runner.momentum, runner.weight_decay,
+                                      1.0 / gdist.world_size(), True, hyper=runner.hyper)
+        done.extend(ranges)
 
     def after_train_iter(self, runner):
         from ..hip import ops
@@ -90,20 +142,33 @@ class ArenaOptimizerHook(Hook):
         t0 = time.perf_counter() if prof is not None else 0.0
         ops.SIDE_CHECKPOINT = None
         ops.DEFER_JOIN = True          # the tapes hand their weight gradients over but do not join
+        runner.mark("fwd_end")
+        done = []
+        if self.EARLY and runner.arena.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            ops.BACKWARD_MARK_CB = lambda tag: self._early_step(runner, tag, done)
         try:
             runner.outputs["loss"].backward()
         finally:
             ops.DEFER_JOIN = False
+            ops.BACKWARD_MARK_CB = None
         t1 = time.perf_counter() if prof is not None else 0.0
+        runner.mark("bwd_end_main")
+        for i, sd in enumerate(ops._side_streams.get((runner.arena.device.type, runner.arena.device.index), ())):
+            runner.mark("bwd_end_side%d" % i, sd)
         ops.join_branch_streams()      # (auxiliary head / shortcut work on the branch stream)
         runner.reducer.finish()
         scale = 1.0 / gdist.world_size()
         early, late = runner.split_ranges()
+        if done:
+            done.sort()
+            early, late = _ranges_subtract(early, done), _ranges_subtract(late, done)
+            runner.early_steps += 1
         ck = ops.SIDE_CHECKPOINT
         if ck is not None and early:
             # gradients of everything behind the checkpoint are final once the side stream has passed
             # it: update those parameters while the stem / stage-1 weight gradients still run
-            torch.cuda.current_stream().wait_event(ck)
+            for ev in ck:
+                torch.cuda.current_stream().wait_event(ev)
             runner.arena.sgd_step(early, runner.lr, runner.momentum, runner.weight_decay, scale, True,
                                   hyper=runner.hyper)
             ops.join_side_streams()
@@ -113,8 +178,11 @@ class ArenaOptimizerHook(Hook):
             ops.join_side_streams()
             runner.arena.sgd_step(runner.active_ranges, runner.lr, runner.momentum,
                                   runner.weight_decay, scale, True, hyper=runner.hyper)
+        if done:   # the next forward reads those parameters on this stream
+            ops.join_from(ops.opt_stream(runner.arena.device), runner.arena.device)
         # the step cleared exactly the ranges backward wrote: the next zero_grad has nothing to do
         runner.arena.grads_clean = True
+        runner.mark("step_end")
         if prof is not None:
             prof["backward"] = prof.get("backward", 0.0) + (t1 - t0)
             prof["finish+sgd"] = prof.get("finish+sgd", 0.0) + (time.perf_counter() - t1)
@@ -182,6 +250,9 @@ class IterBasedRunner:
         self.arch_key = None
         self.arch_meta = None
         self._split_cache = {}
+        self._early_cache = {}
+        self.early_steps = 0           # optimizer steps whose first instalment ran inside backward
+        self.step_events = {} if os.environ.get("GS_STEP_EVENTS") else None
         self._active_cache = {}
         # GS_HOST_PROF=1: accumulate host-side seconds per phase of train_iter (diagnostics)
         self.host_prof = {} if os.environ.get("GS_HOST_PROF") else None
@@ -200,6 +271,30 @@ class IterBasedRunner:
 
     def register_hook(self, hook):
         self.hooks.append(hook)
+
+    # ---- GS_STEP_EVENTS=1 (diagnostics): HIP events at the phase boundaries of every step, on the
+    # stream the phase ends on; bench.py prints the mean offsets from the step's start.  Unlike a
+    # profiler trace this does not slow the host down, so it shows the real critical path.
+    def mark(self, name, stream=None):
+        ev = self.step_events
+        if ev is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream if stream is not None else torch.cuda.current_stream())
+        ev.setdefault(name, []).append(e)
+
+    def step_event_summary(self):
+        """{phase: mean ms from 'step_begin'} over the recorded steps (call after a synchronize)."""
+        ev = self.step_events
+        if not ev or "step_begin" not in ev:
+            return {}
+        n = len(ev["step_begin"])
+        out = {}
+        for name, lst in ev.items():
+            if name == "step_begin" or len(lst) != n:
+                continue
+            out[name] = sum(b.elapsed_time(e) for b, e in zip(ev["step_begin"], lst)) / n
+        return out
 
     def call_hook(self, name):
         for h in self.hooks:
@@ -240,6 +335,28 @@ class IterBasedRunner:
                 self._active_cache[key] = hit
         self.active_params, self.trainable_params = hit
         self.active_ranges = self.arena.ranges_for(self.trainable_params, key)
+
+    def early_ranges(self):
+        """Arena ranges of the trainable parameters whose gradients are final when backward crosses
+        the backbone's "stage2|stage3" mark: stages 3.. and everything outside the backbone."""
+        key = self.arch_key if self.arch_key != ("current",) else None
+        cached = self._early_cache.get(key) if key is not None else None
+        if cached is not None:
+            return cached
+        bb = getattr(self.model, "backbone", None)
+        fn = getattr(bb, "early_gradient_parameters", None)
+        if fn is None:
+            out = []
+        else:
+            bb_ids = {id(p) for p in bb.parameters()}
+            early_ids = {id(p) for p in fn()}
+            out = self.arena.ranges_for([p for p in self.trainable_params
+                                         if id(p) in early_ids or id(p) not in bb_ids])
+        if key is not None:
+            if len(self._early_cache) > 1024:
+                self._early_cache.clear()
+            self._early_cache[key] = out
+        return out
 
     def split_ranges(self):
         """(early, late) parts of active_ranges: `late` covers the parameters whose weight gradients
@@ -367,6 +484,7 @@ class IterBasedRunner:
     def train_iter(self, data_batch):
         prof = self.host_prof
         t0 = time.perf_counter() if prof is not None else 0.0
+        self.mark("step_begin")
         if not self.model.training:   # (a full module walk: ~1.5 ms of host time per call)
             self.model.train()
         self.call_hook("before_train_iter")

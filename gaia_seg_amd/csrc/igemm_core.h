@@ -1743,33 +1743,41 @@ __global__ __launch_bounds__(NT) void igemm_wgrad_fast_kernel(const IgemmArgs p)
 // Fixed-order sum of the split-K partial slabs + epilogue.  rows_are_taps selects the wgrad
 // output addressing.
 // WIDE = false: one thread per output float4 walks the splits (few splits, many outputs).
-// WIDE = true : one wave per output float4, lanes stride over the splits and combine with a fixed
-//               xor butterfly (many splits, few outputs: stage-1 wgrad has 256 splits of a 64x256
-//               tile — the serial form spent 75 us there on 256 dependent-latency loads).
+// WIDE = true : many splits, few outputs (stage-1 / stem weight gradients: 256 splits of a 64 x 256
+//               tile).  A block is 16 adjacent output quads x 16 split groups: thread (q, g) sums the
+//               slabs g, g + 16, ... of its quad — the 16 quads of a slab row are 256 contiguous
+//               bytes, so every load instruction reads whole lines, and a thread's splits / 16 loads
+//               are independent — and the 16 group sums are combined through LDS in group order.
+//               (r03 form: one wave per quad with the lanes striding over the slabs, 16 B out of every
+//               line it touched: 37-117 us per launch at the end of backward, where the side stream
+//               is the critical path.)  Fixed order: bit-reproducible.
 template <bool WIDE, int ROLE = 0>
 static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, int splits,
                                                                    int rows_are_taps) {
   const int qpr = p.Nn / 4;
   const long total = (long)p.M * qpr;
-  const int lane = threadIdx.x & 63;
-  const long first = WIDE ? ((long)blockIdx.x * 4 + (threadIdx.x >> 6))
+  __shared__ f32x4 red[WIDE ? 256 : 1];
+  const int qi = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long first = WIDE ? ((long)blockIdx.x * 16 + qi)
                           : ((long)blockIdx.x * blockDim.x + threadIdx.x);
-  const long stride = WIDE ? (long)gridDim.x * 4 : (long)gridDim.x * blockDim.x;
-  for (long idx = first; idx < total; idx += stride) {
-    const int row = (int)(idx / qpr);
-    const int col = (int)(idx - (long)row * qpr) * 4;
+  const long stride = WIDE ? (long)gridDim.x * 16 : (long)gridDim.x * blockDim.x;
+  const long bound = WIDE ? ((total + 15) / 16) * 16 : total;   // WIDE: whole blocks reach the barriers
+  for (long idx = first; idx < bound; idx += stride) {
+    const bool live = idx < total;
+    const int row = live ? (int)(idx / qpr) : 0;
+    const int col = live ? (int)(idx - (long)row * qpr) * 4 : 0;
     f32x4 v{0.f, 0.f, 0.f, 0.f};
     if (WIDE) {
-      for (int z = lane; z < splits; z += 64)
-        v += *reinterpret_cast<const f32x4*>(p.slab + ((long)z * p.M + row) * p.Nn + col);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        v[0] += __shfl_xor(v[0], off, 64);
-        v[1] += __shfl_xor(v[1], off, 64);
-        v[2] += __shfl_xor(v[2], off, 64);
-        v[3] += __shfl_xor(v[3], off, 64);
+      if (live)
+        for (int z = grp; z < splits; z += 16)
+          v += *reinterpret_cast<const f32x4*>(p.slab + ((long)z * p.M + row) * p.Nn + col);
+      red[grp * 16 + qi] = v;
+      __syncthreads();
+      if (grp == 0) {
+        for (int g = 1; g < 16; ++g) v += red[g * 16 + qi];
       }
-      if (lane != 0) continue;
+      __syncthreads();
+      if (grp != 0 || !live) continue;
     } else {
       v = *reinterpret_cast<const f32x4*>(p.slab + (long)row * p.Nn + col);
       for (int z = 1; z < splits; ++z)
@@ -2183,8 +2191,10 @@ static inline void launch_reduce(const IgemmArgs& a, int splits, int rows_are_ta
   if (role == 1 && splits < 48) {
     hipLaunchKernelGGL((splitk_reduce_kernel<false, 1>), dim3(stream_grid(total, 256)), dim3(256), 0,
                        st, a, splits, rows_are_taps);
-  } else if (splits >= 48) {
-    const int grid = (int)std::min<long>(ceil_div(total, 4), (long)num_cu() * 16);
+  } else if (splits >= 48 || (splits >= 16 && total < 65536)) {
+    // few outputs per slab: spread the slabs over 16 thread groups (one thread per output quad would
+    // leave most of the chip idle behind `splits` loads each)
+    const int grid = (int)std::min<long>(ceil_div(total, 16), (long)num_cu() * 16);
     hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(grid), dim3(256), 0, st, a, splits,
                        rows_are_taps);
   } else {

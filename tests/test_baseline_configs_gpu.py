@@ -2,7 +2,7 @@
 
   config 1  FCN + the [64,128,256,512]/[2,2,2,2] bottleneck subnet ("R18-like": the reference has no
             BasicBlock, dynamic_resnet.py:132-133), 512x512, bs 2, forward + backward
-  config 2  FCN + R50..R101 supernet, 1024x512, bs 2: anchors MIN, MAX and a seeded random draw (R50: config 5)
+  config 2  FCN + R50..R101 supernet, 1024x512, bs 2: anchors R50, MIN, MAX and a seeded random draw
   config 3  PSP + aux FCN (the reference's pspnet_ar50to101v2_gsync model), 1024x512, bs 2, one rank
   config 4  UPer + R101 anchor, 769x769, bs 4 (every tile edge is ragged at 193/97/49/25)
   OS8       the reference's v1c supernet (deep stem, dilations (1,1,2,4)) + PSP + aux, R50 anchor,
@@ -13,6 +13,9 @@
 Protocol: tests/parity.py — one HIP step vs one fp64 oracle pass on the HIP path's ReLU branch
 pattern; losses, accuracy, BN running statistics and all parameter gradients at 1e-3 max norm, with
 the bounded conditioning rule of tests/parity.py for parameters where fp32 itself cannot hold 1e-3.
+And north_star's sentence literally (r04): the HIP logits and losses against the oracle's OWN fp32
+forward -- PyTorch-CPU fp32 on its own ReLU branches, no shared masks -- at 1e-3 of the largest logit
+(check_native_fp32; the numbers go to profiles/r04_parity_margins.md).
 Weights: the real supernet at its real (max) sizes, random conv weights with He scale, BN gamma in
 U(0.5, 1.5), beta N(0, 0.1), norm3 not zeroed, dropout 0."""
 import os
@@ -20,8 +23,8 @@ import os
 import pytest
 import torch
 
-from parity import (check_flips, compare_step, fp32_witness_masks, hip_train_step, oracle_step,
-                    train_step_parity)
+from parity import (check_flips, check_native_fp32, compare_step, fp32_witness_masks, hip_train_step,
+                    oracle_step, train_step_parity)
 from util_models import make_pair
 
 pytestmark = pytest.mark.gpu
@@ -135,10 +138,10 @@ def _train_case(name, arch, n, h, w, **head_updates):
 
 
 # ---- config 2 -------------------------------------------------------------------------------
-# (the R50 anchor of this supernet is compared -- losses, BN statistics, every gradient -- by
-# test_config5_ohem_train_step_2048x1024 at the same pixel count, and its losses once more by
-# bench.py's first-step gate; the GPU suite has a time budget, so it is not run a third time here)
-@pytest.mark.parametrize("anchor", ["MIN", "MAX"])
+# (R50 is 5 of the 20 draws of the headline bench line: losses, BN statistics, every gradient, and --
+# like every case here -- the logits against the oracle's own fp32 forward, tests/parity.py
+# check_native_fp32)
+@pytest.mark.parametrize("anchor", ["R50", "MIN", "MAX"])
 def test_config2_fcn_supernet_1024x512_bs2(hip_lib, anchor):
     _train_case("fcn_ar50to101v2.py", ANCHORS[anchor], 2, 512, 1024)
 
@@ -219,7 +222,9 @@ def test_config5_ohem_train_step_2048x1024(hip_lib):
         check_flips(ctx, masks)
         # the selections agree except for pixels whose probability is within rounding of the threshold
         assert ties and ties[-1] <= max(4, n_kept // 50000), ties
-        compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=True, check_buffers=False)
+        native = check_native_fp32(out, ctx.logits)
+        compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=True, check_buffers=False,
+                     native=native)
     finally:
         orc.decode_head.sampler = None
         prod.decode_head.sampler = None

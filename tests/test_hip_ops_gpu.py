@@ -348,6 +348,41 @@ def test_fused_resize_ce_fwd_bwd(hip_lib, shape):
         assert rel_err(lg.grad, lr.grad * 2.5) < 5e-5
 
 
+@pytest.mark.parametrize("shape,align", [
+    (((1, 19, 193, 193), (769, 769)), False),   # config 4's loss: ratio 3.98, ~16-pixel tiles, ragged borders
+    (((2, 19, 25, 25), (97, 97)), True),        # align_corners: the last source row / column is hit exactly
+    (((2, 45, 5, 7), (21, 30)), False),         # 45 classes: three class passes per tile; ratios 4.2 x 4.29
+    (((1, 19, 9, 6), (10, 47)), True),          # nearly 1:1 along H (tiles of one row), 7.8 along W
+    (((2, 19, 4, 4), (31, 29)), False),         # ~56 pixels per tile: four passes of a 16-lane row
+])
+def test_fused_resize_ce_backward_row_tiles(hip_lib, shape, align):
+    """The any-scale tile form of the loss backward (csrc/loss.hip ce_bwd_rowtile_kernel: one 16-lane
+    row per tile, every softmax term once) against F.interpolate + F.cross_entropy on the CPU, with
+    pixel weights, class weights and ignored pixels."""
+    from gaia_seg_amd.hip.runtime import Act
+    from gaia_seg_amd.models.losses import seg_loss_and_accuracy
+    (n, c, h, w), size = shape
+    torch.manual_seed(1)
+    logits = torch.randn(n, c, h, w) * 3
+    label = torch.randint(0, c, (n, *size))
+    label[:, :2, :] = 255
+    label[0, 3:8, 1:6] = 255
+    pw = (torch.rand(n, *size) > 0.3).float()
+    for weight, cw in [(None, None), (pw, torch.rand(c) + 0.5)]:
+        lr = logits.clone().requires_grad_(True)
+        loss_r, acc_r = _ce_ref(lr, label, size, weight=weight, cw=cw, lw=0.4, align=align)
+        loss_r.backward()
+        a = Act.empty(n, h, w, c, torch.device(DEV))
+        a.t.copy_(logits.permute(0, 2, 3, 1))
+        lg = a.as_nchw().requires_grad_(True)
+        loss, acc = seg_loss_and_accuracy(lg, label.to(DEV),
+                                          weight.to(DEV) if weight is not None else None,
+                                          cw.to(DEV) if cw is not None else None, 255, align, 0.4)
+        assert abs(float(loss) - float(loss_r)) < 2e-5 * max(1.0, abs(float(loss_r)))
+        (loss * 2.5).backward()
+        assert rel_err(lg.grad, lr.grad * 2.5) < 5e-5
+
+
 def test_sgd_step_matches_torch(hip_lib):
     import ctypes
     from gaia_seg_amd.hip import lib

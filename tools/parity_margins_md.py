@@ -25,6 +25,23 @@ def main(src, dst):
         lines.append("| %s | %d | %d | %.2f | %.2f | %.2f | %.2e | %.2e | %.1e |" % (
             r["test"].split("::")[-1], r["parameters"], r["conditioned"], r["ratio_median"], r["ratio_p90"],
             r["ratio_max"], r["hip_err_max_conditioned"], r["worst_unconditioned"], r["loss_err"]))
+    nat = [r for r in recs if r.get("native_fp32")]
+    if nat:
+        lines += ["", "## HIP forward vs the oracle's OWN fp32 forward (no shared ReLU masks)", "",
+                  "`north_star`: \"the same logits / loss as the reference CPU path within 1e-3 rel fp32\".  Logits in "
+                  "the max norm relative to the largest logit; `witness` = the fp32 oracle against the fp64 pass "
+                  "(what two fp32 evaluations of this network may differ by); bound 1e-3 where witness <= 1e-3 / 3, "
+                  "else 3 x witness (tests/parity.py `check_native_fp32`).", "",
+                  "| test | head | HIP vs fp32 oracle | witness (fp32 oracle vs fp64) | loss_seg rel err |",
+                  "|---|---|---|---|---|"]
+        for r in nat:
+            n = r["native_fp32"]
+            for k, v in n.items():
+                if k.startswith("logits."):
+                    head = k[len("logits."):]
+                    loss = n.get("loss.%s.loss_seg" % head)
+                    lines.append("| %s | %s | %.2e | %.2e | %s |" % (
+                        r["test"].split("::")[-1], head, v[0], v[1], "%.1e" % loss if loss is not None else "-"))
     single = [r["test"].split("::")[-1] for r in recs if r.get("single_source")]
     if single:
         lines += ["", "Single-source steps (p90 / p10 of the ratios < 1.25: every conditioned gradient inherits one "
