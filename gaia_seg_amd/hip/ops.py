@@ -264,6 +264,11 @@ def reserve_workspaces(dev, nbytes=192 << 20):
 BRANCH = os.environ.get("GS_BRANCH", "1") != "0"
 BRANCH_SHORTCUT = BRANCH and os.environ.get("GS_BRANCH_SHORTCUT", "1") != "0"
 BRANCH_AUX = BRANCH and os.environ.get("GS_BRANCH_AUX", "1") != "0"
+# GS_AUX_PREFORK=1: the auxiliary heads' stream forks behind the stage they read (they then run beside
+# the later stages too) instead of behind the whole backbone (beside the decode head only).  Measured
+# (profiles/r04_stream_experiments.md): no faster, and the stage-4 K3 launches share the chip with the
+# auxiliary head's 3x3 (K3 0.574 vs 0.582 of peak on R50) -- default off.
+AUX_PREFORK = os.environ.get("GS_AUX_PREFORK", "0") == "1"
 SLOT_SHORTCUT, SLOT_AUX = 1, 2   # scratch slot / branch stream index (0 = the training stream)
 _branch_streams = {}     # (device type, index, slot) -> torch.cuda.Stream
 _branch_slot_of = {}     # raw stream handle -> slot (adopt_current_stream)

@@ -191,7 +191,7 @@ class DynamicResNet(nn.Module, DynamicMixin):
         last = len(self.res_layers) - 1
         for i, layer_name in enumerate(self.res_layers):
             x = getattr(self, layer_name).forward_act(tape, x)
-            if i == fork_stage and i < last and tape.enabled and ops.BRANCH_AUX:
+            if i == fork_stage and i < last and tape.enabled and ops.BRANCH_AUX and ops.AUX_PREFORK:
                 # the auxiliary heads' inputs are complete: their branch stream starts from here
                 ops.prefork_branch(x.t.device, ops.SLOT_AUX)
                 self.__dict__["_aux_forked"] = True
