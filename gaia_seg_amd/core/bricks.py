@@ -525,6 +525,13 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
                 if isinstance(m, DynamicConv2d):
                     m.manipulate_width(width * self.expansion)
 
+    def _shortcut_gflop(self, x):
+        """2 * rows * Ci * Co of the projection shortcut's 1x1 conv for input activation x, in GFLOP."""
+        conv = next(m for m in self.downsample if isinstance(m, DynamicConv2d))
+        s = max(self.stride, 1)
+        rows = x.N * ((x.H + s - 1) // s) * ((x.W + s - 1) // s)
+        return 2e-9 * rows * x.C * conv.width_state
+
     def _shortcut_act(self, tape, x, defer_residual=False):
         """The projection shortcut: [AvgPool2d,] 1x1 conv, norm (dynamic_res_layer.py:70-94).
         ``defer_residual``: leave the norm to the residual add of norm3's apply pass."""
@@ -569,7 +576,11 @@ class DynamicBottleneck(nn.Module, DynamicMixin):
             # conv1's accumulates onto it after the join, so conv1 owns the input gradient here too.
             # The shortcut's BatchNorm is applied inside norm3's apply pass (relu(bn3(y3) + bn_s(y_s))):
             # its normalised output is never stored.
-            br = ops.Branch(tape, x.t.device, ops.BRANCH_SHORTCUT)
+            # (only where the shortcut is a small launch: at OS8 the stage-3/4 shortcuts are 17-69 GF
+            # convolutions that fill the chip alone and only take it away from the block's K3 launch:
+            # K3 0.77 -> 0.64 of peak on the v1c supernet with no gain in images/s)
+            small = self._shortcut_gflop(x) <= ops.BRANCH_SHORTCUT_MAX_GFLOP
+            br = ops.Branch(tape, x.t.device, ops.BRANCH_SHORTCUT and small)
             with br:
                 identity = self._shortcut_act(tape, x, ops.DEFER_SHORTCUT_BN
                                               and fused_call_ok(conv3, norm3))

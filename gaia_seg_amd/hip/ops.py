@@ -264,6 +264,7 @@ def reserve_workspaces(dev, nbytes=192 << 20):
 BRANCH = os.environ.get("GS_BRANCH", "1") != "0"
 BRANCH_SHORTCUT = BRANCH and os.environ.get("GS_BRANCH_SHORTCUT", "1") != "0"
 BRANCH_AUX = BRANCH and os.environ.get("GS_BRANCH_AUX", "1") != "0"
+BRANCH_SHORTCUT_MAX_GFLOP = float(os.environ.get("GS_BRANCH_SHORTCUT_MAX_GFLOP", "8"))
 # GS_AUX_PREFORK=1: the auxiliary heads' stream forks behind the stage they read (they then run beside
 # the later stages too) instead of behind the whole backbone (beside the decode head only).  Measured
 # (profiles/r04_stream_experiments.md): no faster, and the stage-4 K3 launches share the chip with the

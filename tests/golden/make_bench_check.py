@@ -50,7 +50,9 @@ def main():
     if args.arch == "sample":
         meta = sampler.sample()
     else:
-        meta = {a["name"]: a for a in sampler.model_samplers[0].anchors}[args.arch]
+        meta = dict({a["name"]: a for a in sampler.model_samplers[0].anchors}[args.arch])
+        if cfg.get("stem_anchors"):   # deep-stem (v1c / OS8) supernet: a width per stem conv (as bench.py)
+            meta["arch.backbone.stem.width"] = list(cfg["stem_anchors"][args.arch])
     bs = cfg.data["samples_per_gpu"]
     h, w = cfg.crop_size
     mcfg = {k: v for k, v in _plain(cfg.model).items() if k != "type"}
