@@ -121,6 +121,13 @@ class GradReducer:
         self.group = group
         self.hole_frac = hole_frac
         self.collectives = 0          # launches handed to the backend (a coalesced group counts once)
+        self._no_coalesce = False
+        # GS_CHECK_HOLES=1 (debug): before a bucket goes out, assert that the padded holes inside its
+        # runs (gradients of parameters the sampled subnet does not use) are exactly zero on this rank
+        # -- a stale value there would be summed over the ranks every step and consumed when the block
+        # becomes active (synchronises the host: diagnostics only)
+        import os
+        self.check_holes = os.environ.get("GS_CHECK_HOLES") == "1"
         self._plans = {}
         self._active = None
         self._works = []
@@ -254,14 +261,25 @@ class GradReducer:
         else as one call per run."""
         tensors = [self.flat_grad[a:b] for a, b in runs]
         self.bytes_reduced += sum(t.numel() * t.element_size() for t in tensors)
-        if len(tensors) > 1 and self._coalescing():
-            from torch.distributed.distributed_c10d import _coalescing_manager
-            with _coalescing_manager(group=self.group, async_ops=True) as cm:
-                for t in tensors:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            self._works.append(cm)
-            self.collectives += 1
-            return
+        if self.check_holes:
+            self._assert_holes_zero(runs)
+        if len(tensors) > 1 and self._coalescing() and not self._no_coalesce:
+            # torch's coalescing manager is a private API (and has only ever run on a one-rank RCCL
+            # group in this pipeline): if it is missing or its signature has changed, fall back to one
+            # call per run for the rest of the process instead of failing every multi-GPU step
+            try:
+                from torch.distributed.distributed_c10d import _coalescing_manager
+                with _coalescing_manager(group=self.group, async_ops=True) as cm:
+                    for t in tensors:
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            except (ImportError, TypeError, AttributeError) as e:
+                import warnings
+                warnings.warn("grouped RCCL launch unavailable (%s): one all-reduce per run" % (e,))
+                self._no_coalesce = True
+            else:
+                self._works.append(cm)
+                self.collectives += 1
+                return
         for t in tensors:
             self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
@@ -282,6 +300,22 @@ class GradReducer:
             if launched:
                 runs.extend(st["plan"][bi]["runs"])
         return runs
+
+    def _assert_holes_zero(self, runs):
+        st = self._active
+        if st is None:
+            return
+        active = sorted(self.segments[pid] for b in st["plan"] for pid in b["param_ids"])
+        for a, b in runs:
+            cur = a
+            for o, n in active:
+                if o + n <= a or o >= b:
+                    continue
+                if o > cur and float(self.flat_grad[cur:o].abs().max()) != 0.0:
+                    raise AssertionError("non-zero gradient in the padded hole [%d, %d) of a bucket" % (cur, o))
+                cur = max(cur, o + n)
+            if cur < b and float(self.flat_grad[cur:b].abs().max()) != 0.0:
+                raise AssertionError("non-zero gradient in the padded hole [%d, %d) of a bucket" % (cur, b))
 
     def finish(self):
         """Flush buckets whose parameters never reported (no gradient this step) and wait."""

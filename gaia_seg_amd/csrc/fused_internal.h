@@ -28,6 +28,16 @@ int bn_tile_finalize(const float* part, int np, int bm, long rows, int C, const 
                      const float* beta, float eps, float momentum, float* running_mean,
                      float* running_var, float* coeffs, hipStream_t st);
 
+// stem.hip: the 7x7 stride-2 stem convolution of the NCHW image (forward with BatchNorm tile partials,
+// weight gradient); stem_conv_ok says whether a descriptor takes these kernels
+bool stem_conv_ok(const gs_conv_desc* d);
+bool stem_wgrad_on();   // the weight-gradient kernel is opt-in (GS_STEM_WGRAD=1): see stem.hip
+size_t stem_wgrad_slab_bytes(const gs_conv_desc* d);
+int stem_forward(const gs_conv_desc* d, const float* x, const float* w, float* y, float* tile_stats,
+                 int* np, hipStream_t st);
+int stem_wgrad(const gs_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
+               size_t workspace_bytes, hipStream_t st);
+
 // norm.hip: z = relu?((y - mean) * scale + beta + ((residual - rmean) * rscale + rbeta)), optional mask
 int bn_apply_resaff(const float* x, int64_t rows, int32_t C, int32_t ldx, const float* coeffs,
                     const float* residual, int32_t ld_res, const float* rcoeffs, int32_t relu, float* y,

@@ -86,6 +86,23 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
     if (!aligned16(d->in_affine)) return GS_E_ALIGN;
     a.a_coeffs = d->in_affine;
   }
+  // the stem: 7x7 stride-2 conv of the 3-channel NCHW image (stem.hip)
+  if (!vec && !bias && !addend && stem_conv_ok(d)) {
+    const int tiles = d->N * d->Ho * (d->Wo / 128);
+    float* ts = nullptr;
+    int mode = 0;
+    if (want_stats && info && workspace && aligned16(workspace) &&
+        (size_t)3 * d->Co * tiles * sizeof(float) <= workspace_bytes) {
+      ts = static_cast<float*>(workspace);
+      mode = 1;
+    }
+    if (info) {
+      info->mode = mode; info->splits = 1; info->tiles_m = tiles; info->bm = 128;
+      info->slab = nullptr; info->slab_bytes = 0; info->timed = false;
+      info->flops = 2.0 * (double)M * d->Co * d->Ci * d->KH * d->KW;
+    }
+    return stem_forward(d, x, w, y, ts, nullptr, st);
+  }
   // short-K 1x1 convs over many rows: the streaming kernel (igemm_stream.h)
   const StreamPlan sp = stream_fwd_plan(d, fast, bias, addend);
   if (sp.ok) {
@@ -185,6 +202,17 @@ extern "C" int gs_debug_query_conv_launch(const gs_conv_desc* d, int32_t op, gs_
   Plan pl{};
   int kloop = GS_KLOOP_GENERIC;
   const bool aff = d->in_affine != nullptr && op != GS_OP_DGRAD;
+  if (!vec && (op == GS_OP_FORWARD || (op == GS_OP_WGRAD && stem_wgrad_on())) && stem_conv_ok(d)) {
+    // stem.hip: 128-row tiles, its own loops
+    const int tiles = d->N * d->Ho * (d->Wo / 128);
+    if (op == GS_OP_FORWARD) pl = Plan{128, d->Co, 1, 37, 37, tiles, 1};
+    else {
+      const int groups = (int)(stem_wgrad_slab_bytes(d) / ((size_t)147 * d->Co * sizeof(float)));
+      pl = Plan{128, d->Co, groups, tiles, (int)ceil_div(tiles, groups), 1, 1};
+    }
+    *out = gs_debug_launch{op, GS_KLOOP_GENERIC, pl.bm, pl.bn, pl.splits, pl.nk_per_split, 0, 0};
+    return GS_OK;
+  }
   if (op == GS_OP_FORWARD) {
     pl = plan_fwd(d);
     const size_t src_b = (size_t)d->N * d->x_sn * sizeof(float);

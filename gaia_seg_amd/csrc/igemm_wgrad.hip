@@ -1,12 +1,13 @@
 // DynConv2d weight gradient (implicit GEMM over pixels, split-K) — see igemm_core.h
 #include "igemm_core.h"
+#include "fused_internal.h"
 
 using namespace gs;
 
 // slab bytes of the weight-gradient path gs_conv2d_wgrad takes for this descriptor
 size_t gs_wgrad_slab_bytes(const gs_conv_desc* d) {
   const Plan pl = plan_wgrad(d);
-  return slab_bytes(pl, (long)d->KH * d->KW * d->Ci, d->Co);
+  return std::max(slab_bytes(pl, (long)d->KH * d->KW * d->Ci, d->Co), stem_wgrad_slab_bytes(d));
 }
 
 extern "C" int gs_conv2d_wgrad(const gs_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -17,6 +18,8 @@ extern "C" int gs_conv2d_wgrad(const gs_conv_desc* d, const float* x, const floa
   if (!aligned16(dy) || !aligned16(dw)) return GS_E_ALIGN;
   const bool vec = x_is_vector(d);
   if (vec && !aligned16(x)) return GS_E_ALIGN;
+  if (!vec && stem_wgrad_on() && stem_conv_ok(d))   // the stem: stem.hip
+    return stem_wgrad(d, x, dy, dw, workspace, workspace_bytes, as_stream(stream));
   const Plan pl = plan_wgrad(d);
   const long M = (long)d->KH * d->KW * d->Ci;
   const size_t need = slab_bytes(pl, M, d->Co);

@@ -10,7 +10,7 @@ import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
 from ...core.bricks import (DynamicBatchNorm2d, DynamicBottleneck, DynamicConv2d,
-                            build_conv_layer, build_norm_layer, constant_init, kaiming_init)
+                            build_conv_layer, build_norm_layer, constant_init, conv_bn_act, kaiming_init)
 from ...core.dynamic import DynamicMixin, freeze, unzip_meta
 from ...hip import ops
 from ...hip.runtime import tape_function
@@ -178,11 +178,11 @@ class DynamicResNet(nn.Module, DynamicMixin):
         if self.deep_stem:
             mods = list(self.stem)
             for i in range(0, len(mods), 3):  # conv, norm, relu triples
-                x = mods[i].forward_act(tape, x)
-                x = mods[i + 1].forward_act(tape, x, relu=True)
+                x = conv_bn_act(tape, mods[i], mods[i + 1], x, relu=True)
         else:
-            x = self.conv1.forward_act(tape, x)
-            x = self.norm1.forward_act(tape, x, relu=True)
+            # (one library call: the stem kernel's epilogue leaves the BatchNorm tile partials, so the
+            # separate statistics pass over the 67 MB output is gone — csrc/stem.hip)
+            x = conv_bn_act(tape, self.conv1, self.norm1, x, relu=True)
         mp = self.maxpool
         x = ops.maxpool(tape, x, mp.kernel_size, mp.stride, mp.padding)
         outs = []

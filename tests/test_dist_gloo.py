@@ -60,6 +60,28 @@ def _worker_reducer(rank, world, port, q):
         p._gs_grad_ready(p)
     red2.finish()
     ok = ok and grouped and bool(torch.allclose(flat, want))
+    # padded holes (hole_frac = 1: everything between the runs travels along) with the debug check on:
+    # zero holes pass, a stale value in a hole is caught before it would be summed over the ranks
+    for stale in (False, True):
+        flat.copy_(local)
+        for i in (2, 4):
+            o, n = segs[id(params[i])]
+            flat[o:o + n] = 0.0
+        if stale:
+            flat[segs[id(params[2])][0] + 3] = 1.0
+        red3 = GradReducer(flat, segs, bucket_bytes=4 * 4000, hole_frac=1.0)
+        red3.check_holes = True
+        red3.begin(active, key=None)
+        caught = False
+        try:
+            for p in reversed(active):
+                p._gs_grad_ready(p)
+            red3.finish()
+        except AssertionError:
+            caught = True
+        ok = ok and (caught == stale)
+        if caught:      # keep the ranks' collectives paired: the other rank raised at the same point
+            red3._active, red3._works = None, []
     q.put((rank, ok, red.bytes_reduced))
     dist.destroy_process_group()
 
