@@ -208,11 +208,17 @@ def check_flips(ctx, masks):
     return total
 
 
-def _acc_err(got, want, npix):
+def _acc_err(got, want, npix, fp32_native=None):
     """accuracy (percent) is a step function of the logits: allow argmax ties — 2 pixels, or 2e-5
-    of the pixels at full size (random-init logits of 19 classes are all within ~1e-2 of each other; measured: 12 of 1.18 M pixels for the UPer head at 769x769)."""
+    of the pixels at full size (random-init logits of 19 classes are all within ~1e-2 of each other;
+    measured: 12 of 1.18 M pixels for the UPer head at 769x769), or — where the network amplifies fp32
+    rounding until more pixels than that sit on a tie (config 2 MAX: logits 2e-3 from fp64) — 3 x the
+    number of pixels by which the oracle's OWN fp32 forward differs from the fp64 pass."""
     flips = abs(got - want) / 100.0 * npix
-    return 0.0 if flips <= max(2.01, 2e-5 * npix) else flips
+    allowed = max(2.01, 2e-5 * npix)
+    if fp32_native is not None:
+        allowed = max(allowed, COND_FACTOR * abs(fp32_native - want) / 100.0 * npix)
+    return 0.0 if flips <= allowed else flips
 
 
 def compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=True, check_buffers=True,
@@ -223,7 +229,8 @@ def compare_step(prod, orc, out, losses_o, loss_o, gt, check_grads=True, check_b
     extra_draws = 0
     for k, v in losses_o.items():
         if k.endswith("acc_seg"):
-            errs[k] = _acc_err(float(out["log_vars"][k]), float(v), float(gt.numel()))
+            errs[k] = _acc_err(float(out["log_vars"][k]), float(v), float(gt.numel()),
+                               NATIVE_FP32.get("losses", {}).get(k) if native is not None else None)
         else:
             errs[k] = abs(float(out["log_vars"][k]) - float(v)) / max(abs(float(v)), 1e-6)
     errs["loss"] = abs(float(out["loss"]) - float(loss_o)) / abs(float(loss_o))
