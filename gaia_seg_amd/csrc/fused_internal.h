@@ -31,7 +31,7 @@ int bn_tile_finalize(const float* part, int np, int bm, long rows, int C, const 
 // stem.hip: the 7x7 stride-2 stem convolution of the NCHW image (forward with BatchNorm tile partials,
 // weight gradient); stem_conv_ok says whether a descriptor takes these kernels
 bool stem_conv_ok(const gs_conv_desc* d);
-bool stem_wgrad_on();   // the weight-gradient kernel is opt-in (GS_STEM_WGRAD=1): see stem.hip
+bool stem_wgrad_on();   // GS_STEM_WGRAD=0 puts the weight gradient back on the generic kernel
 size_t stem_wgrad_slab_bytes(const gs_conv_desc* d);
 int stem_forward(const gs_conv_desc* d, const float* x, const float* w, float* y, float* tile_stats,
                  int* np, hipStream_t st);

@@ -5,7 +5,7 @@
 // arithmetic (K = 7 * 7 * 3 = 147 is not a multiple of anything, the source is NCHW with three
 // channels): r04 trace 121 us forward (2.5 GF: 20 TF) + a separate 17 us statistics pass, 114 us weight
 // gradient (4.9 GF: 43 TF) -- in EVERY step whatever the sampled subnet, the forward at the head of the
-// dependent chain, the weight gradient at the very end of backward.
+// dependent chain, the weight gradient at the very end of backward.  Here: 67 us and 82-91 us.
 //
 // Here a workgroup owns 128 consecutive output pixels of ONE output row: their receptive field is a
 // 3 x 7 x 261 patch of the image (22 KB) that is loaded once, coalesced along W, zero-filled outside
@@ -55,144 +55,226 @@ __device__ __forceinline__ int stem_koff(int k) {
   return (c * 7 + kh) * kStemPWp + kw;
 }
 
+// One element of the patch under tile (n, ho, wo0): flat index i in [0, 3 * 7 * 261)
+__device__ __forceinline__ float stem_patch_elem(const float* __restrict__ xb, long x_sc, long x_sh, int H,
+                                                 int W, int ho, int wo0, int i) {
+  const int ck = i / kStemPW;
+  const int j = i - ck * kStemPW;
+  const int c = ck / 7, kh = ck - c * 7;
+  const int hi = 2 * ho - 3 + kh, wi = 2 * wo0 - 3 + j;
+  return (hi >= 0 && hi < H && wi >= 0 && wi < W) ? xb[(long)c * x_sc + (long)hi * x_sh + wi] : 0.f;
+}
+constexpr int kStemPre = (3 * 7 * kStemPW + 255) / 256;   // patch elements per thread (22)
+
+// Forward.  Persistent workgroups (two per CU): the weights [147][Co] go to LDS once; the patch of the
+// NEXT tile is fetched into registers while the MFMA loop of the current one runs, so the loop never
+// waits for global memory (the first version loaded, computed and stored one tile per workgroup and ran
+// at 107 us: r04 trace).  The C tile goes out through the patch's LDS in two 64-row halves.
 template <int NB>   // Co = 16 * NB
-__global__ __launch_bounds__(256) void stem7x7_fwd_kernel(
+__global__ __launch_bounds__(256, 2) void stem7x7_fwd_kernel(
     const float* __restrict__ x, long x_sn, long x_sc, long x_sh, int H, int W,
     const float* __restrict__ w, int co_ld, float* __restrict__ y, int ldy, int Ho, int Wo,
-    int tiles_per_row, float* __restrict__ tile_stats, int np) {
+    int tiles_per_row, int tiles_total, float* __restrict__ tile_stats, int np) {
   constexpr int CO = 16 * NB, WP = CO + 8, KP = 148, PC = CO + 4;
   constexpr int LDSF = kStemPatch + KP * WP;
-  static_assert(128 * PC + 2 * 256 <= LDSF, "C staging + statistics scratch fit behind the operands");
+  static_assert(64 * PC + 2 * 256 <= kStemPatch, "half a C tile + statistics scratch fit in the patch area");
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
   float* patch = lds;
   float* Wl = lds + kStemPatch;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, kq = lane >> 4;
-  const int tile = blockIdx.x;
-  const int seg = tile % tiles_per_row;
-  const int r = tile / tiles_per_row;
-  const int ho = r % Ho, n = r / Ho;
-  const int wo0 = seg * kStemTW;
-  stem_load_patch(patch, x, x_sn, x_sc, x_sh, H, W, n, ho, wo0, t);
   for (int i = t; i < KP * (CO / 4); i += 256) {
     const int k = i / (CO / 4), q = i - k * (CO / 4);
     f32x4 v{0.f, 0.f, 0.f, 0.f};
     if (k < kStemK) v = *reinterpret_cast<const f32x4*>(w + (long)k * co_ld + q * 4);
     *reinterpret_cast<f32x4*>(Wl + k * WP + q * 4) = v;
   }
-  __syncthreads();
-  f32x4 acc[2][NB];
+  float pre[kStemPre];
+  auto fetch = [&](int tile) {
+    const int seg = tile % tiles_per_row;
+    const int r = tile / tiles_per_row;
+    const int ho = r % Ho, n = r / Ho;
+    const float* xb = x + (long)n * x_sn;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < kStemPre; ++u) {
+      const int i = t + u * 256;
+      pre[u] = i < 3 * 7 * kStemPW ? stem_patch_elem(xb, x_sc, x_sh, H, W, ho, seg * kStemTW, i) : 0.f;
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < tiles_total) fetch(tile);
   const int p0 = 2 * (wave * 32 + li);       // patch column of this lane's pixel in row block 0
-#pragma unroll 2
-  for (int kk = 0; kk < KP / 4; ++kk) {
-    const int k = kk * 4 + kq;
-    const int koff = stem_koff(k);
-    float a[2], b[NB];
-    a[0] = patch[koff + p0];
-    a[1] = patch[koff + p0 + 32];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) b[j] = Wl[k * WP + j * 16 + li];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-  }
-  __syncthreads();                            // everybody is done with the operands
-  float* Cs = lds;                            // [128][PC]
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        Cs[(wave * 32 + i * 16 + kq * 4 + e) * PC + j * 16 + li] = acc[i][j][e];
-  __syncthreads();
-  const long m0 = ((long)n * Ho + ho) * Wo + wo0;
-  for (int idx = t; idx < kStemTW * (CO / 4); idx += 256) {
-    const int row = idx / (CO / 4), q = idx - row * (CO / 4);
-    if (wo0 + row < Wo)
-      *reinterpret_cast<f32x4*>(y + (m0 + row) * ldy + q * 4) =
-          *reinterpret_cast<const f32x4*>(&Cs[row * PC + q * 4]);
-  }
-  if (tile_stats) {   // (the host hands a statistics buffer only when every tile is full)
-    constexpr int G = 256 / CO;
-    float* red = lds + 128 * PC;              // [2][G][CO]
-    const int c = t % CO, rg = t / CO;
-    float s1 = 0.f, s2 = 0.f;
-    const float shift = Cs[c];
-    if (rg < G) {
-      for (int rr = rg; rr < kStemTW; rr += G) {
-        const float v = Cs[rr * PC + c] - shift;
-        s1 += v;
-        s2 += v * v;
-      }
-      red[rg * CO + c] = s1;
-      red[(G + rg) * CO + c] = s2;
-    }
-    __syncthreads();
-    if (rg == 0) {
-      for (int g = 1; g < G; ++g) {
-        s1 += red[g * CO + c];
-        s2 += red[(G + g) * CO + c];
-      }
-      const long C4 = CO >> 2;
-      const int cq = c >> 2, e = c & 3;
-      tile_stats[((0 * C4 + cq) * np + tile) * 4 + e] = s1;
-      tile_stats[((1 * C4 + cq) * np + tile) * 4 + e] = s2;
-      tile_stats[((2 * C4 + cq) * np + tile) * 4 + e] = shift;
-    }
-  }
-}
-
-template <int NB>
-__global__ __launch_bounds__(256) void stem7x7_wgrad_kernel(
-    const float* __restrict__ x, long x_sn, long x_sc, long x_sh, int H, int W,
-    const float* __restrict__ dy, int ldy, float* __restrict__ slab, int Ho, int Wo, int tiles_per_row,
-    int tiles_total, int tiles_per_wg) {
-  constexpr int CO = 16 * NB, DP = CO + 8;
-  constexpr int LDSF = kStemPatch + kStemTW * DP;
-  static_assert(4 * 16 * CO <= LDSF, "cross-wave reduction scratch fits");
-  __shared__ __attribute__((aligned(16))) float lds[LDSF];
-  float* patch = lds;
-  float* dyl = lds + kStemPatch;              // [128][DP]
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, kq = lane >> 4;
-  f32x4 acc[10][NB];
-#pragma unroll
-  for (int i = 0; i < 10; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int koff[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) koff[i] = stem_koff(i * 16 + li);   // (rows >= 147 are never stored)
-  const int first = blockIdx.x * tiles_per_wg;
-  const int last = min(first + tiles_per_wg, tiles_total);
-  for (int tile = first; tile < last; ++tile) {
+  constexpr int G = 256 / CO;                // statistics: G row groups x CO columns
+  const int sc = t % CO, srg = t / CO;
+  for (; tile < tiles_total; tile += gridDim.x) {
     const int seg = tile % tiles_per_row;
     const int r = tile / tiles_per_row;
     const int ho = r % Ho, n = r / Ho;
     const int wo0 = seg * kStemTW;
-    __syncthreads();                          // the previous tile's operands are no longer read
-    stem_load_patch(patch, x, x_sn, x_sc, x_sh, H, W, n, ho, wo0, t);
-    const long m0 = ((long)n * Ho + ho) * Wo + wo0;
-    for (int idx = t; idx < kStemTW * (CO / 4); idx += 256) {
-      const int row = idx / (CO / 4), q = idx - row * (CO / 4);
-      f32x4 v{0.f, 0.f, 0.f, 0.f};
-      if (wo0 + row < Wo) v = *reinterpret_cast<const f32x4*>(dy + (m0 + row) * ldy + q * 4);
-      *reinterpret_cast<f32x4*>(dyl + row * DP + q * 4) = v;
+    __syncthreads();                          // the previous tile's C halves have left the patch area
+#pragma unroll
+    for (int u = 0; u < kStemPre; ++u) {
+      const int i = t + u * 256;
+      if (i < 3 * 7 * kStemPW) {
+        const int ck = i / kStemPW;
+        patch[ck * kStemPWp + (i - ck * kStemPW)] = pre[u];
+      }
     }
     __syncthreads();
-#pragma unroll 1
-    for (int pg = 0; pg < 8; ++pg) {
-      const int p = wave * 32 + pg * 4 + kq;  // this lane's pixel of the contraction group
+    if (tile + (int)gridDim.x < tiles_total) fetch(tile + gridDim.x);   // in flight during the MFMA loop
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int kk = 0; kk < KP / 4; ++kk) {
+      const int k = kk * 4 + kq;
+      const int koff = stem_koff(k);
+      float a[2], b[NB];
+      a[0] = patch[koff + p0];
+      a[1] = patch[koff + p0 + 32];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) b[j] = Wl[k * WP + j * 16 + li];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    // C tile -> LDS (the patch area) -> coalesced rows, in two halves of 64 rows (waves 0-1, waves 2-3)
+    float* Cs = lds;                          // [64][PC]
+    float* red = lds + 64 * PC;               // [2][G][CO]
+    const long m0 = ((long)n * Ho + ho) * Wo + wo0;
+    float s1 = 0.f, s2 = 0.f, shift = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();                        // operands / the previous half are no longer read
+      if ((wave >> 1) == half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              Cs[((wave & 1) * 32 + i * 16 + kq * 4 + e) * PC + j * 16 + li] = acc[i][j][e];
+      }
+      __syncthreads();
+      for (int idx = t; idx < 64 * (CO / 4); idx += 256) {
+        const int row = idx / (CO / 4), q = idx - row * (CO / 4);
+        if (wo0 + half * 64 + row < Wo)
+          *reinterpret_cast<f32x4*>(y + (m0 + half * 64 + row) * ldy + q * 4) =
+              *reinterpret_cast<const f32x4*>(&Cs[row * PC + q * 4]);
+      }
+      if (tile_stats && srg < G) {            // (a statistics buffer only when every tile is full)
+        if (half == 0) shift = Cs[sc];        // the tile's first row
+        for (int rr = srg; rr < 64; rr += G) {
+          const float v = Cs[rr * PC + sc] - shift;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (tile_stats) {
+      if (srg < G) {
+        red[srg * CO + sc] = s1;
+        red[(G + srg) * CO + sc] = s2;
+      }
+      __syncthreads();
+      if (srg == 0) {
+        for (int g = 1; g < G; ++g) {
+          s1 += red[g * CO + sc];
+          s2 += red[(G + g) * CO + sc];
+        }
+        const long C4 = CO >> 2;
+        const int cq = sc >> 2, e = sc & 3;
+        tile_stats[((0 * C4 + cq) * np + tile) * 4 + e] = s1;
+        tile_stats[((1 * C4 + cq) * np + tile) * 4 + e] = s2;
+        tile_stats[((2 * C4 + cq) * np + tile) * 4 + e] = shift;
+      }
+    }
+  }
+}
+
+// Weight gradient.  Persistent workgroups; waves (0, 1) own tap rows 0..79, waves (2, 3) rows 80..159,
+// and inside a pair the two waves split the tile's 128 pixels — 5 x Co/16 accumulator blocks per wave,
+// which leaves registers for the NEXT tile's patch and dy rows, fetched while the MFMA loop of the
+// current tile runs (the first version kept 10 x Co/16 blocks per wave and loaded, computed, loaded:
+// 107 us alone, 289 us beside the optimizer's HBM traffic).
+template <int NB>
+__global__ __launch_bounds__(256, 2) void stem7x7_wgrad_kernel(
+    const float* __restrict__ x, long x_sn, long x_sc, long x_sh, int H, int W,
+    const float* __restrict__ dy, int ldy, float* __restrict__ slab, int Ho, int Wo, int tiles_per_row,
+    int tiles_total) {
+  constexpr int CO = 16 * NB, DP = CO + 8;
+  constexpr int LDSF = kStemPatch + kStemTW * DP;
+  constexpr int DYV = (kStemTW * (CO / 4) + 255) / 256;   // dy float4 per thread and tile (8 at Co = 64)
+  static_assert(2 * 16 * CO <= LDSF, "cross-wave reduction scratch fits");
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  float* patch = lds;
+  float* dyl = lds + kStemPatch;              // [128][DP]
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, kq = lane >> 4;
+  const int rhalf = wave >> 1, phalf = wave & 1;           // tap-row half, pixel half
+  f32x4 acc[5][NB];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int koff[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) koff[i] = stem_koff((rhalf * 5 + i) * 16 + li);   // (rows >= 147: never stored)
+  float pre[kStemPre];
+  f32x4 pdy[DYV];
+  auto fetch = [&](int tile) {
+    const int seg = tile % tiles_per_row;
+    const int r = tile / tiles_per_row;
+    const int ho = r % Ho, n = r / Ho;
+    const int wo0 = seg * kStemTW;
+    const float* xb = x + (long)n * x_sn;
+#pragma unroll
+    for (int u = 0; u < kStemPre; ++u) {
+      const int i = t + u * 256;
+      pre[u] = i < 3 * 7 * kStemPW ? stem_patch_elem(xb, x_sc, x_sh, H, W, ho, wo0, i) : 0.f;
+    }
+    const long m0 = ((long)n * Ho + ho) * Wo + wo0;
+#pragma unroll
+    for (int u = 0; u < DYV; ++u) {
+      const int idx = t + u * 256;
+      const int row = idx / (CO / 4), q = idx - row * (CO / 4);
+      pdy[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < kStemTW * (CO / 4) && wo0 + row < Wo)
+        pdy[u] = *reinterpret_cast<const f32x4*>(dy + (m0 + row) * ldy + q * 4);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < tiles_total) fetch(tile);
+  for (; tile < tiles_total; tile += gridDim.x) {
+    __syncthreads();                          // the previous tile's operands are no longer read
+#pragma unroll
+    for (int u = 0; u < kStemPre; ++u) {
+      const int i = t + u * 256;
+      if (i < 3 * 7 * kStemPW) {
+        const int ck = i / kStemPW;
+        patch[ck * kStemPWp + (i - ck * kStemPW)] = pre[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DYV; ++u) {
+      const int idx = t + u * 256;
+      if (idx < kStemTW * (CO / 4)) {
+        const int row = idx / (CO / 4), q = idx - row * (CO / 4);
+        *reinterpret_cast<f32x4*>(dyl + row * DP + q * 4) = pdy[u];
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < tiles_total) fetch(tile + gridDim.x);   // in flight during the MFMA loop
+#pragma unroll 2
+    for (int pg = 0; pg < 16; ++pg) {
+      const int p = phalf * 64 + pg * 4 + kq;   // this lane's pixel of the contraction group
       float b[NB];
 #pragma unroll
       for (int j = 0; j < NB; ++j) b[j] = dyl[p * DP + j * 16 + li];
 #pragma unroll
-      for (int i = 0; i < 10; ++i) {
+      for (int i = 0; i < 5; ++i) {
         const float a = patch[koff[i] + 2 * p];
 #pragma unroll
         for (int j = 0; j < NB; ++j)
@@ -200,35 +282,37 @@ __global__ __launch_bounds__(256) void stem7x7_wgrad_kernel(
       }
     }
   }
-  // the four waves hold partial sums over different pixels: add them (wave order) and store the slab
-  float* red = lds;                           // [4][16][CO]
+  // the two waves of a pair hold partial sums over different pixels: add them (fixed order) and store
+  float* red = lds;                           // [2 pixel halves][16][CO], one tap-row half at a time
   float* out = slab + (long)blockIdx.x * kStemK * CO;
 #pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    __syncthreads();
+  for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+    for (int i = 0; i < 5; ++i) {
+      __syncthreads();
+      if (rhalf == rh) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        red[(wave * 16 + kq * 4 + e) * CO + j * 16 + li] = acc[i][j][e];
-    __syncthreads();
-    for (int idx = t; idx < 16 * CO; idx += 256) {
-      const int row = idx / CO, k = i * 16 + row;
-      if (k < kStemK)
-        out[(long)k * CO + (idx - row * CO)] =
-            ((red[idx] + red[16 * CO + idx]) + red[2 * 16 * CO + idx]) + red[3 * 16 * CO + idx];
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            red[(phalf * 16 + kq * 4 + e) * CO + j * 16 + li] = acc[i][j][e];
+      }
+      __syncthreads();
+      for (int idx = t; idx < 16 * CO; idx += 256) {
+        const int row = idx / CO, k = (rh * 5 + i) * 16 + row;
+        if (k < kStemK) out[(long)k * CO + (idx - row * CO)] = red[idx] + red[16 * CO + idx];
+      }
     }
-  }
 }
 
-// MEASURED (r04, R50 step under rocprofv3, 1024 x 512 bs 2): forward 107 us against the generic
-// kernel's 121 us + the 17 us statistics pass + its sum / finalize it makes unnecessary (~30 us per
-// step saved); weight gradient 107 us alone / up to 289 us beside the optimizer's HBM traffic against
-// 114 + 7 us for the generic kernel + reduce -- the single-buffered load -> compute -> store tile
-// loop does not hide its loads.  So the forward is ON, the weight gradient is opt-in
-// (GS_STEM_WGRAD=1) until its tile loop prefetches.
+// MEASURED (r04, R50 step under rocprofv3, 1024 x 512 bs 2).  First version (one tile per workgroup,
+// load -> compute -> store): forward 107 us, weight gradient 107 us alone / up to 289 us beside the
+// optimizer's HBM traffic -- no better than the generic kernels (121 + 17 us statistics pass; 114 + 7 us
+// reduce).  This version (persistent workgroups, next tile's operands prefetched into registers
+// during the MFMA loop): forward 67 us, weight gradient 82-91 us.  GS_STEM_WGRAD=0 / GS_NO_STEM_KERNEL=1
+// put the weight gradient / both back on the generic kernels.
 bool stem_wgrad_on() {
-  static const bool on = getenv("GS_STEM_WGRAD") != nullptr && getenv("GS_STEM_WGRAD")[0] == '1';
+  static const bool on = !(getenv("GS_STEM_WGRAD") != nullptr && getenv("GS_STEM_WGRAD")[0] == '0');
   return on;
 }
 
@@ -245,9 +329,9 @@ bool stem_conv_ok(const gs_conv_desc* d) {
 
 static inline int stem_wgrad_groups(const gs_conv_desc* d, int* tiles_per_wg) {
   const int tiles = d->N * d->Ho * (d->Wo / kStemTW);
-  const int want = std::min(tiles, 2 * num_cu());
-  *tiles_per_wg = (int)ceil_div(tiles, want);
-  return (int)ceil_div(tiles, *tiles_per_wg);
+  const int groups = std::min(tiles, 2 * num_cu());      // persistent: tiles dealt round-robin
+  *tiles_per_wg = (int)ceil_div(tiles, groups);
+  return groups;
 }
 
 size_t stem_wgrad_slab_bytes(const gs_conv_desc* d) {
@@ -262,7 +346,7 @@ int stem_forward(const gs_conv_desc* d, const float* x, const float* w, float* y
   const int tpr = d->Wo / kStemTW;
   const int tiles = d->N * d->Ho * tpr;
   if (np) *np = tiles;
-  const dim3 grid(tiles), block(256);
+  const dim3 grid(std::min(tiles, 2 * num_cu())), block(256);
   Plan pl{};
   pl.bm = kStemTW; pl.bn = d->Co; pl.splits = 1; pl.nk_total = pl.nk_per_split = 37;
   pl.tiles_m = tiles; pl.tiles_n = 1;
@@ -270,8 +354,8 @@ int stem_forward(const gs_conv_desc* d, const float* x, const float* w, float* y
               2.0 * d->N * d->Ho * (double)d->Wo * d->Co * kStemK);
 #define GS_STEM_FWD(NB)                                                                              \
   hipLaunchKernelGGL((stem7x7_fwd_kernel<NB>), grid, block, 0, st, x, (long)d->x_sn, (long)d->x_sc,  \
-                     (long)d->x_sh, d->H, d->W, w, d->Co_ld, y, d->ldy, d->Ho, d->Wo, tpr, tile_stats, \
-                     tiles)
+                     (long)d->x_sh, d->H, d->W, w, d->Co_ld, y, d->ldy, d->Ho, d->Wo, tpr, tiles,    \
+                     tile_stats, tiles)
   if (d->Co == 64) GS_STEM_FWD(4);
   else if (d->Co == 48) GS_STEM_FWD(3);
   else GS_STEM_FWD(2);
@@ -297,7 +381,7 @@ int stem_wgrad(const gs_conv_desc* d, const float* x, const float* dy, float* dw
 #define GS_STEM_WG(NB)                                                                               \
   hipLaunchKernelGGL((stem7x7_wgrad_kernel<NB>), dim3(groups), dim3(256), 0, st, x, (long)d->x_sn,   \
                      (long)d->x_sc, (long)d->x_sh, d->H, d->W, dy, d->ldy, slab, d->Ho, d->Wo, tpr,  \
-                     tiles, tpw)
+                     tiles)
   if (d->Co == 64) GS_STEM_WG(4);
   else if (d->Co == 48) GS_STEM_WG(3);
   else GS_STEM_WG(2);

@@ -17,7 +17,7 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 TOL = 3e-5
-WGRAD_ON = os.environ.get("GS_STEM_WGRAD", "0") == "1"   # the weight-gradient kernel is opt-in
+WGRAD_ON = os.environ.get("GS_STEM_WGRAD", "1") != "0"   # GS_STEM_WGRAD=0: generic weight-gradient kernel
 
 # co_max co  n  h    w     stem kernels?
 CASES = [
@@ -79,13 +79,13 @@ def test_stem_forward_and_weight_gradient(hip_lib, case):
         assert (q.bm == 128) == (stem and (op == lib.OP_FORWARD or WGRAD_ON))
 
 
-def test_stem_weight_gradient_kernel_opt_in():
-    """The same cases with GS_STEM_WGRAD=1 (child interpreter: the switch is read once)."""
+def test_same_cases_with_the_generic_weight_gradient():
+    """The same cases with GS_STEM_WGRAD=0 (child interpreter: the switch is read once)."""
     import subprocess
     import sys
-    if WGRAD_ON:
-        pytest.skip("already the opt-in run")
-    env = dict(os.environ, GS_STEM_WGRAD="1")
+    if not WGRAD_ON:
+        pytest.skip("already the GS_STEM_WGRAD=0 run")
+    env = dict(os.environ, GS_STEM_WGRAD="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
                         "-k", "forward_and_weight_gradient"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
