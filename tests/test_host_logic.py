@@ -323,3 +323,46 @@ def test_training_step_leaves_no_reference_cycles():
         assert res.returncode == 0, res.stderr[-2000:]
         out = json.loads(res.stdout.strip().splitlines()[-1])
         assert out["unreachable_per_step"] == 0, (cfg, out)
+
+
+def test_range_arithmetic_of_the_optimizer_instalments():
+    """core/runner.py splits the active arena ranges into instalments: what the early step updated is
+    subtracted from what remains.  Disjoint sorted [begin, end) lists."""
+    from gaia_seg_amd.core.runner import _ranges_intersect, _ranges_subtract
+    a = [(0, 10), (20, 30), (40, 50)]
+    assert _ranges_subtract(a, []) == a
+    assert _ranges_subtract(a, [(0, 50)]) == []
+    assert _ranges_subtract(a, [(5, 25)]) == [(0, 5), (25, 30), (40, 50)]
+    assert _ranges_subtract(a, [(2, 3), (4, 6), (28, 45)]) == [(0, 2), (3, 4), (6, 10), (20, 28), (45, 50)]
+    assert _ranges_intersect(a, [(5, 25), (45, 60)]) == [(5, 10), (20, 25), (45, 50)]
+    assert _ranges_intersect(a, []) == []
+    # a partition: (a - b) and (a & b) tile a
+    b = [(3, 22), (29, 41)]
+    parts = sorted(_ranges_subtract(a, b) + _ranges_intersect(a, b))
+    assert sum(e - s for s, e in parts) == sum(e - s for s, e in a)
+    assert all(x[1] <= y[0] for x, y in zip(parts, parts[1:]))
+
+
+def test_bench_plan_only_needs_no_gpu():
+    """`bench.py --plan-only --gpus 8`: the data-parallel exchange plan from host arithmetic alone
+    (bucket planner over the arena layout); one JSON object, no GPU touched."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--plan-only", "--gpus", "8",
+                        "--steps", "4"], capture_output=True, text=True, cwd=root,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["plan_only"] and d["n_gpus"] == 8 and d["arena_bytes"] > 4e8
+    per = d["per_step"]
+    assert set(per) >= {"MIN", "R50", "MAX", "mix_of_4_draws_mean"}
+    for name in ("MIN", "R50", "MAX"):
+        p = per[name]
+        assert p["collective_launches"] == p["buckets"] == len(p["bucket_bytes"])
+        assert sum(p["bucket_bytes"]) == p["allreduce_bytes"] >= p["active_parameter_bytes"]
+        assert p["padded_hole_bytes"] <= 0.05 * p["allreduce_bytes"] + 1
+        assert p["syncbn_collectives"] == 2 * p["syncbn_layers"] and p["expected_allreduce_ms"] > 0
+    assert per["MIN"]["allreduce_bytes"] < per["R50"]["allreduce_bytes"] < per["MAX"]["allreduce_bytes"]
+    assert per["MAX"]["allreduce_bytes"] == d["arena_bytes"]      # MAX uses every parameter

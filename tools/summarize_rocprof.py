@@ -29,6 +29,10 @@ def group(name):
             return K3
         kind = "conv dgrad" if t[2] == "true" else "conv forward"
         return "%s %s" % (kind, {"1": "1x1", "3": "3x3"}.get(t[3], "other"))
+    if "stem7x7_fwd_kernel" in name:
+        return "conv forward stem/other"
+    if "stem7x7_wgrad_kernel" in name:
+        return "conv wgrad stem/other"
     if "conv1x1_stream_kernel" in name:      # <BNW, BTRANS, AFF>
         t = name.split("<")[1].split(">")[0].split(", ")
         return "%s 1x1" % ("conv dgrad" if t[1] == "true" else "conv forward")
