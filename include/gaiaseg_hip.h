@@ -87,7 +87,10 @@ int gs_conv2d_in_affine_supported(const gs_conv_desc* d);
 /* bytes of split-K scratch the three calls below may use for this descriptor (max of the three) */
 size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d);
 
-/* y[n,ho,wo,:Co] = conv(x, w[:, :, :Ci, :Co]) (+ bias[:Co]) (+ addend).  bias/addend may be NULL. */
+/* y[n,ho,wo,:Co] = conv(x, w[:, :, :Ci, :Co]) (+ bias[:Co]) (+ addend).  bias/addend may be NULL.
+ * The network's stem -- 7x7, stride 2, pad 3, Ci = Ci_max = 3 on the NCHW image, Co in {32, 48, 64},
+ * Wo % 128 == 0 (gaiaseg/models/backbones/dynamic_resnet.py:290-297) -- has its own forward and
+ * weight-gradient kernels (csrc/stem.hip); gs_debug_last_conv_launch reports them as 128-row tiles. */
 int gs_conv2d_forward(const gs_conv_desc* d, const float* x, const float* w, const float* bias,
                       const float* addend, float* y, void* workspace, size_t workspace_bytes,
                       void* stream);
@@ -375,8 +378,12 @@ int gs_ce_backward(const gs_ce_desc* d, const float* logits, const int64_t* labe
  * align_corners = 0 (every mmseg head of this path: x8 / x16 / x32): one workgroup per tile of
  * full-resolution pixels between four low-resolution logit pixels evaluates each softmax term once
  * (the gather form of gs_ce_backward evaluates it once per neighbour, i.e. four times), then a
- * fixed-order gather adds the four corner sums per low-resolution pixel.  Falls back to
- * gs_ce_backward otherwise.  workspace >= gs_ce_backward_workspace_bytes(d, ld_d). */
+ * fixed-order gather adds the four corner sums per low-resolution pixel.  Any OTHER up-scaling of at
+ * most 64 full-resolution pixels per tile on average (config 4's 193 -> 769, align_corners either way)
+ * takes the row-tile form (r04): the same tiles, bounds found with the resize's own source-index
+ * arithmetic, one 16-lane DPP row per tile.  Falls back to gs_ce_backward otherwise (larger
+ * non-power-of-two ratios, down-scaling).  workspace >= gs_ce_backward_workspace_bytes(d, ld_d), which
+ * is 0 exactly when the gather form will be used. */
 size_t gs_ce_backward_workspace_bytes(const gs_ce_desc* d, int32_t ld_d);
 int gs_ce_backward_ws(const gs_ce_desc* d, const float* logits, const int64_t* labels,
                       const float* pixel_weight, const float* class_weight, const float* lse,
@@ -545,8 +552,8 @@ int gs_debug_last_conv_launch(gs_debug_launch* out);
 int gs_debug_conv_launch_counts(int64_t* counts, int32_t reset);
 /* flops[op * GS_KLOOP_COUNT + kloop] (15 entries) = algorithmic FLOPs (2 * M * N * K of the implicit GEMM, padding not counted)
  * launched since the last reset: bench.py states which share of a step's contraction work ran on
- * which MFMA path, so that its roofline fractions name the right bound.  Not thread-safe (one
- * launching thread at a time, like the training step). */
+ * which MFMA path, so that its roofline fractions name the right bound.  The forward thread and the
+ * autograd thread may both launch: the counters are updated atomically. */
 int gs_debug_conv_launch_flops(double* flops, int32_t reset);
 /* Forward convolutions on the bf16x3 K loop: 0 = never (fp32 MFMA loops), 1 = the shapes where it
  * measured ahead (3x3, not where the two-steps-per-barrier fp32 loop runs unsplit), 2 = every launch
