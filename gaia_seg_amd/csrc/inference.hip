@@ -170,9 +170,170 @@ __global__ __launch_bounds__(256) void slide_fuse_kernel(const SlideArgs a,
   }
 }
 
+// ---- label map only, no rescale: one thread per strip of kStrip output pixels of a row -------------
+// The per-pixel kernel above reads the four corner vectors of every covering window for every pixel:
+// 80 16-byte L1 loads per pixel under four windows (r03 / r04 profiles: config 5 slide 98 / 91 us, whole
+// 50 / 39 us -- bound by L1 load issue, not by the 17 MB label map).  Neighbouring pixels of a row share
+// their low-resolution cell: a thread that walks kStrip consecutive pixels keeps the cell's four
+// corner vectors in registers, shifts them when the walk enters the next cell (new left column = old
+// right column) and loads only the new right column -- a quarter of the loads.  The arithmetic is the
+// per-pixel kernel's, expression by expression and window by window (ATen's upsample_bilinear2d
+// order, then the division by the cover count), so the label maps are bit-identical
+// (tests/test_inference_ohem_gpu.py).
+constexpr int kStrip = 4;
+constexpr int kStripCQ = 5;     // class quads in registers: ld <= 20 (19 Cityscapes classes)
+int g_slide_strip = -1;         // -1: GS_SLIDE_STRIP (default 1); gs_debug_set_slide_strip
+
+// state of the walk through one window: the four corner vectors (NQ class quads) of the current cell
+template <int NQ>
+struct StripCell {
+  f32x4 p00[NQ], p01[NQ], p10[NQ], p11[NQ];
+  int i0, i1;
+};
+
+template <int Q0, int NQ>
+__device__ __forceinline__ void strip_pixel(StripCell<NQ>& cell, f32x4 (&acc)[NQ], bool live, int lx_,
+                                            const SlideArgs& a, const Lerp& ly,
+                                            const f32x4* __restrict__ r0, const f32x4* __restrict__ r1) {
+  if (!live) return;
+  const Lerp lx = lerp_coord(lx_, a.sw, a.d.wl, a.d.align_corners);
+  if (lx.i0 != cell.i0 || lx.i1 != cell.i1) {
+    if (lx.i0 == cell.i1 && cell.i0 >= 0) {   // next cell: the old right column is the new left one
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { cell.p00[q] = cell.p01[q]; cell.p10[q] = cell.p11[q]; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        cell.p00[q] = r0[lx.i0 * kStripCQ + Q0 + q];
+        cell.p10[q] = r1[lx.i0 * kStripCQ + Q0 + q];
+      }
+    }
+    if (lx.i1 == lx.i0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { cell.p01[q] = cell.p00[q]; cell.p11[q] = cell.p10[q]; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        cell.p01[q] = r0[lx.i1 * kStripCQ + Q0 + q];
+        cell.p11[q] = r1[lx.i1 * kStripCQ + Q0 + q];
+      }
+    }
+    cell.i0 = lx.i0; cell.i1 = lx.i1;
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    acc[q] += ly.l0 * (lx.l0 * cell.p00[q] + lx.l1 * cell.p01[q]) +
+              ly.l1 * (lx.l0 * cell.p10[q] + lx.l1 * cell.p11[q]);
+}
+
+// One pass over the covering windows for class quads [Q0, Q0 + NQ): the class range is split in two
+// passes (12 + 8 classes) so that the corner vectors and the four pixels' sums of a pass fit in ~120
+// registers -- four waves per SIMD instead of two; the kernel waits on dependent L1 / L2 loads, not on
+// arithmetic.  Updates the running (max, arg max) of the strip's four pixels.
+template <int Q0, int NQ>
+__device__ __forceinline__ void strip_pass(const SlideArgs& a, const float* __restrict__ logits, int n,
+                                           int sy, int sx0, const int (&cnt)[kStrip],
+                                           float (&best)[kStrip], int (&amax)[kStrip]) {
+  const gs_slide_desc& d = a.d;
+  f32x4 acc0[NQ], acc1[NQ], acc2[NQ], acc3[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    acc0[q] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[q] = acc0[q]; acc2[q] = acc0[q]; acc3[q] = acc0[q];
+  }
+#pragma unroll 1
+  for (int iy = 0; iy < d.ny; ++iy) {
+    const int ly_ = sy - a.ys[iy];
+    if (ly_ < 0 || ly_ >= d.hc) continue;
+    const Lerp ly = lerp_coord(ly_, a.sh, d.hl, d.align_corners);
+#pragma unroll 1
+    for (int ix = 0; ix < d.nx; ++ix) {
+      const int wx = a.xs[ix];
+      if (sx0 + kStrip <= wx || sx0 >= wx + d.wc) continue;
+      const float* base = logits + (((long)(iy * d.nx + ix) * d.N + n) * d.hl) * d.wl * d.ld;
+      const f32x4* r0 = reinterpret_cast<const f32x4*>(base + (long)ly.i0 * d.wl * d.ld);
+      const f32x4* r1 = reinterpret_cast<const f32x4*>(base + (long)ly.i1 * d.wl * d.ld);
+      StripCell<NQ> cell;
+      cell.i0 = cell.i1 = -1;
+      const int l0 = sx0 - wx;
+      auto live = [&](int p) {
+        const int X = sx0 + p, lx_ = l0 + p;
+        return X >= 0 && X < d.Wo && lx_ >= 0 && lx_ < d.wc;
+      };
+      strip_pixel<Q0, NQ>(cell, acc0, live(0), l0 + 0, a, ly, r0, r1);
+      strip_pixel<Q0, NQ>(cell, acc1, live(1), l0 + 1, a, ly, r0, r1);
+      strip_pixel<Q0, NQ>(cell, acc2, live(2), l0 + 2, a, ly, r0, r1);
+      strip_pixel<Q0, NQ>(cell, acc3, live(3), l0 + 3, a, ly, r0, r1);
+    }
+  }
+  auto upd = [&](const f32x4 (&acc)[NQ], int p) {
+    const float c_ = (float)cnt[p];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      f32x4 v = acc[q];
+      if (c_ > 1.f) v = v / c_;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = (Q0 + q) * 4 + e;
+        if (c < d.C && v[e] > best[p]) { best[p] = v[e]; amax[p] = c; }
+      }
+    }
+  };
+  upd(acc0, 0); upd(acc1, 1); upd(acc2, 2); upd(acc3, 3);
+}
+
+// ld == 20 exactly (kStripCQ class quads): the Cityscapes heads of this path
+__global__ __launch_bounds__(256) void slide_label_strip_kernel(const SlideArgs a,
+                                                                const float* __restrict__ logits,
+                                                                int64_t* __restrict__ labels) {
+  const gs_slide_desc& d = a.d;
+  const int spr = (d.Wo + kStrip - 1) / kStrip;           // strips per row
+  // grid = (strips of a row / 256, output rows, images): no index divisions (the per-pixel kernel
+  // spends four 64-bit divisions per pixel on them -- more instructions than its arithmetic)
+  const int oy = blockIdx.y, n = blockIdx.z;
+  for (int js = blockIdx.x * blockDim.x + threadIdx.x; js < spr; js += gridDim.x * blockDim.x) {
+    const int ox0 = js * kStrip;
+    // the view's pixels that land on this strip after the flip back: a horizontal flip mirrors the
+    // strip, so it is walked through source columns sx0 .. sx0 + kStrip - 1 and written mirrored
+    const int sy = d.flip == 2 ? d.Ho - 1 - oy : oy;
+    const int sx0 = d.flip == 1 ? d.Wo - kStrip - ox0 : ox0;   // may be < 0 for the ragged last strip
+    // cover counts: the window list is a product of row and column intervals
+    int cy = 0;
+    for (int iy = 0; iy < d.ny; ++iy) cy += (sy >= a.ys[iy] && sy < a.ys[iy] + d.hc) ? 1 : 0;
+    int cnt[kStrip];
+    float best[kStrip];
+    int amax[kStrip];
+#pragma unroll
+    for (int p = 0; p < kStrip; ++p) {
+      const int X = sx0 + p;
+      int cx = 0;
+      for (int ix = 0; ix < d.nx; ++ix) cx += (X >= a.xs[ix] && X < a.xs[ix] + d.wc) ? 1 : 0;
+      cnt[p] = cy * cx;
+      best[p] = -__builtin_huge_valf();
+      amax[p] = 0;
+    }
+    strip_pass<0, 3>(a, logits, n, sy, sx0, cnt, best, amax);   // classes 0..11 first: the arg max
+    strip_pass<3, 2>(a, logits, n, sy, sx0, cnt, best, amax);   // keeps the FIRST maximum, like the
+#pragma unroll                                                   // per-pixel kernel's class loop
+    for (int p = 0; p < kStrip; ++p) {
+      const int X = sx0 + p;
+      if (X < 0 || X >= d.Wo) continue;
+      const int ox = d.flip == 1 ? d.Wo - 1 - X : X;
+      labels[((long)n * d.Ho + oy) * d.Wo + ox] = amax[p];
+    }
+  }
+}
+
 }  // namespace gs
 
 using namespace gs;
+
+// Test / A-B hook: 1 = the strip kernel for label-only, un-rescaled calls (default), 0 = always the
+// per-pixel kernel, -1 = back to GS_SLIDE_STRIP.
+extern "C" int gs_debug_set_slide_strip(int32_t mode) {
+  if (mode < -1 || mode > 1) return GS_E_BADARG;
+  g_slide_strip = mode;
+  return GS_OK;
+}
 
 extern "C" int gs_slide_fuse(const gs_slide_desc* d, const int32_t* win_y, const int32_t* win_x,
                              const float* logits, const float* probs_in, float* probs_out,
@@ -210,6 +371,17 @@ extern "C" int gs_slide_fuse(const gs_slide_desc* d, const int32_t* win_y, const
   // one wave owns 64 consecutive pixels of an output row; plenty of blocks to fill 256 CUs
   const int grid = (int)std::min<long>(ceil_div(total, 256), (long)num_cu() * 16);
   hipStream_t st = as_stream(stream);
+  if (g_slide_strip < 0) {
+    const char* e = getenv("GS_SLIDE_STRIP");
+    g_slide_strip = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (g_slide_strip && labels && !probs_in && !probs_out && d->Ho == d->H && d->Wo == d->W &&
+      d->ld == 4 * kStripCQ && d->Ho <= 65535 && d->N <= 65535) {
+    const int spr = (int)ceil_div(d->Wo, kStrip);
+    const dim3 sgrid((unsigned)ceil_div(spr, 256), (unsigned)d->Ho, (unsigned)d->N);
+    hipLaunchKernelGGL(slide_label_strip_kernel, sgrid, dim3(256), 0, st, a, logits, labels);
+    return launch_status();
+  }
   if (d->Ho == d->H && d->Wo == d->W)
     hipLaunchKernelGGL(slide_fuse_kernel<false>, dim3(grid), dim3(256), 0, st, a, logits, probs_in,
                        probs_out, labels);

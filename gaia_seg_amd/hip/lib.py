@@ -141,6 +141,7 @@ PROTOTYPES = {
     "gs_ce_label_prob": (_i32, [_CE, _P, _P, _P, _P]),
     "gs_resize_argmax": (_i32, [_CE, _P, _P, _P, _P]),
     "gs_slide_fuse": (_i32, [POINTER(SlideDesc), POINTER(_i32), POINTER(_i32), _P, _P, _P, _P, _P]),
+    "gs_debug_set_slide_strip": (_i32, [_i32]),
     "gs_seg_augment": (_i32, [POINTER(AugmentDesc), _P, _P, _P, _P, _P]),
     "gs_ohem_workspace_bytes": (_sz, []),
     "gs_ohem_weights": (_i32, [_P, _i64, _i64, _f32, _i32, _P, _P, _sz, _P]),

@@ -445,6 +445,10 @@ typedef struct gs_slide_desc {
 int gs_slide_fuse(const gs_slide_desc* d, const int32_t* win_y, const int32_t* win_x,
                   const float* logits, const float* probs_in, float* probs_out, int64_t* labels,
                   void* stream);
+/* Test / A-B hook: label-only, un-rescaled gs_slide_fuse calls walk strips of 4 output pixels that
+ * share their low-resolution cell's corner vectors (mode 1, the default) or use the per-pixel kernel
+ * (mode 0); -1 = back to the GS_SLIDE_STRIP environment value.  Both give bit-identical label maps. */
+int gs_debug_set_slide_strip(int32_t mode);
 
 /* mIoU evaluation support: conf[label*C + pred] += 1 over the pixels
  * whose label != ignore_index; conf is [C*C] uint64, accumulated (zero it before the first call).

@@ -169,6 +169,45 @@ def test_slide_fuse_kernel_matches_oracle(hip_lib, case):
             assert float((top2[:, 0] - top2[:, 1])[d2].max()) < 1e-5
 
 
+@pytest.mark.parametrize("case", [
+    dict(h=96, w=128, crop=(64, 64), stride=(40, 40), low=(8, 8)),                       # 2 x 3 windows, overlaps
+    dict(h=50, w=71, crop=(33, 47), stride=(17, 24), low=(5, 6)),                        # ragged last strip (71 % 4 = 3)
+    dict(h=50, w=70, crop=(64, 64), stride=(32, 32), low=(7, 9), flip="horizontal"),     # mirrored strips, ragged
+    dict(h=65, w=129, crop=(64, 64), stride=(64, 64), low=(8, 8), flip="vertical"),
+    dict(h=64, w=96, crop=None, stride=None, low=(8, 12), align=True),                   # whole mode, align_corners
+    dict(h=128, w=256, crop=(64, 128), stride=(43, 85), low=(8, 16)),                    # config 5's 3 x 3 grid, scaled down
+])
+def test_label_strip_kernel_equals_the_per_pixel_kernel(hip_lib, case):
+    """The label-only, un-rescaled epilogue walks strips of four pixels that share a low-resolution
+    cell (csrc/inference.hip slide_label_strip_kernel); its label map equals the per-pixel kernel's bit
+    for bit -- same expressions, same window order, same division by the cover count."""
+    from gaia_seg_amd.core.inference import FusedInference
+    h, w = case["h"], case["w"]
+    mode = "slide" if case["crop"] else "whole"
+    n, C = 2, 19
+    from gaia_seg_amd.core.inference import window_axes
+    nwin = 1
+    if mode == "slide":
+        ys, xs, hc, wc = window_axes(h, w, case["crop"], case["stride"])
+        nwin = len(ys) * len(xs)
+    g = torch.Generator().manual_seed(11)
+    low = (torch.randn(nwin * n, C, *case["low"], generator=g) * 2).cuda()
+    img = torch.zeros(n, 3, h, w, device="cuda")
+    eng = FusedInference(C, case.get("align", False))
+    maps = []
+    try:
+        for strip in (1, 0):
+            assert hip_lib.gs_debug_set_slide_strip(strip) == 0
+            labels, none = eng(lambda batch: low, img, mode=mode, crop_size=case["crop"],
+                               stride=case["stride"], out_size=(h, w), flip=case.get("flip"))
+            assert none is None
+            maps.append(labels.cpu())
+    finally:
+        hip_lib.gs_debug_set_slide_strip(-1)
+    assert torch.equal(maps[0], maps[1])
+    assert int(maps[0].min()) >= 0 and int(maps[0].max()) < C and maps[0].unique().numel() > 3
+
+
 def test_slide_fuse_rejects_uncovered_images(hip_lib):
     import ctypes
     from gaia_seg_amd.hip import lib
