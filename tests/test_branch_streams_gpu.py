@@ -170,3 +170,21 @@ def test_auxiliary_head_on_its_branch_stream_bitwise(hip_lib):
         assert other.keys() == runs[0].keys()
         for k, v in runs[0].items():
             assert torch.equal(other[k], v), k
+
+
+def test_two_weight_gradient_streams_knob():
+    """GS_SIDE_STREAMS=2 (an experiment knob, default 1: profiles/r04_stream_experiments.md) deals the
+    weight-gradient jobs to two streams; the cases above and a model-level parity test pass under it
+    (child interpreter: the stream count is read at import)."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GS_SIDE_STREAMS", "1") != "1":
+        pytest.skip("already the GS_SIDE_STREAMS run")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, GS_SIDE_STREAMS="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__),
+                        os.path.join(here, "test_model_gpu.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "shortcut_on_the_branch or auxiliary_head_on or fcn_supernet_train_step"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

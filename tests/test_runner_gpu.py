@@ -187,3 +187,34 @@ def test_step_graph_replay_equals_the_eager_step(hip_lib):
     for k in sd_e:
         assert torch.equal(sd_e[k], sd_g[k]), k
     assert int(sd_g["backbone.bn1.num_batches_tracked"]) == 7
+
+
+def test_optimizer_instalment_inside_backward_is_bitwise_the_same_training(hip_lib):
+    """ArenaOptimizerHook.EARLY (GS_EARLY_SGD=1): stages 3.. and the heads are updated on the optimizer
+    stream when backward crosses the backbone's "stage2|stage3" mark, the rest at the end.  Same SGD
+    arithmetic on the same gradients, only the queue and the moment differ: after four steps over two
+    subnets every parameter, momentum buffer and BN statistic equals the default schedule's bit for
+    bit, and the instalment really ran (runner.early_steps)."""
+    from gaia_seg_amd.core.runner import ArenaOptimizerHook
+    from gaia_seg_amd.models import build_segmentor
+    results = []
+    keep = ArenaOptimizerHook.EARLY
+    try:
+        for early in (False, True):
+            ArenaOptimizerHook.EARLY = early
+            torch.manual_seed(0)
+            model = build_segmentor(copy.deepcopy(model_cfg(fcn_head(), aux=True))).cuda().train()
+            runner, arena = _runner(model)
+            for it, name in enumerate(("max", "sub", "max", "min")):
+                runner.set_arch(_anchor(name))
+                runner.train_iter(_batch(it))
+            torch.cuda.synchronize()
+            results.append((runner.early_steps, arena.flat_param.clone(), arena.flat_mom.clone(),
+                            {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    finally:
+        ArenaOptimizerHook.EARLY = keep
+    (n0, p0, m0, b0), (n1, p1, m1, b1) = results
+    assert n0 == 0 and n1 == 4
+    assert torch.equal(p0, p1) and torch.equal(m0, m1)
+    assert b0.keys() == b1.keys() and all(torch.equal(b0[k], b1[k]) for k in b0)
+    assert float(m1.abs().max()) > 0
