@@ -1,7 +1,7 @@
 // Library identification and error text of the gaiaseg_hip C-ABI.
 #include "common.h"
 
-extern "C" int gs_abi_version(void) { return 8; }
+extern "C" int gs_abi_version(void) { return 9; }
 
 extern "C" const char* gs_target_arch(void) { return "gfx950"; }
 
@@ -38,6 +38,8 @@ double g_launch_flops[3][GS_KLOOP_COUNT] = {};
 double g_k3_flops[GS_KLOOP_COUNT] = {};
 int g_stream_mode = -1;
 int g_x3_fwd = -1;
+int g_splitk_inkernel = -1;
+long long g_splitk_combined = 0;
 }
 extern "C" int gs_debug_last_conv_launch(gs_debug_launch* out) {
   if (!out) return GS_E_NULL;
@@ -67,6 +69,20 @@ extern "C" int gs_debug_set_x3_fwd(int32_t mode) {
   if (mode < -1 || mode > 3) return GS_E_BADARG;
   gs::g_x3_fwd = mode;           // -1: back to the environment's GS_X3_FWD (default 3)
   return GS_OK;
+}
+
+// Split-K of the forward / data-gradient row kernels: 1 = the slabs are combined inside the launch by
+// each tile's last-arriving workgroup (default), 0 = a separate reduce launch, -1 = GS_SPLITK_INKERNEL.
+extern "C" int gs_debug_set_splitk_inkernel(int32_t mode) {
+  if (mode < -1 || mode > 1) return GS_E_BADARG;
+  gs::g_splitk_inkernel = mode;
+  return GS_OK;
+}
+
+extern "C" int64_t gs_debug_splitk_combined(int32_t reset) {
+  const long long v = __atomic_load_n(&gs::g_splitk_combined, __ATOMIC_RELAXED);
+  if (reset) __atomic_store_n(&gs::g_splitk_combined, 0LL, __ATOMIC_RELAXED);
+  return v;
 }
 
 extern "C" int gs_debug_num_cu(void) { return gs::num_cu(); }

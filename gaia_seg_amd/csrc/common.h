@@ -9,6 +9,7 @@
 namespace gs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;      // CDNA wavefront
 constexpr int kNumCUDefault = 256;   // MI355X (8 XCDs x 32 CUs)

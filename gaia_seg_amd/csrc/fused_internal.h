@@ -7,6 +7,7 @@ namespace gs {
 struct ConvFwdInfo {
   int mode;          // 0: y complete; 1: per-tile BN partials written; 2: split-K slabs left to reduce
   int splits, tiles_m, bm;
+  const float* tile_part;   // mode 1: where the per-tile partials are (inside the workspace)
   float* slab;       // mode 2: [splits][M][Co]
   size_t slab_bytes;
   bool timed;        // a K3 timer interval is open (mode 2: the caller closes it)
@@ -17,6 +18,13 @@ struct ConvFwdInfo {
 int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, const float* bias,
                         const float* addend, float* y, void* workspace, size_t workspace_bytes,
                         void* stream, bool want_stats, ConvFwdInfo* info);
+
+// Arrival counters of the split-K launches that combine their slabs inside the launch (igemm_core.h
+// splitk_publish): one zero-at-rest buffer per (device, stream), so that launches on different streams
+// never share a counter and launches on one stream reuse it in order.  NULL = not available (switched
+// off with GS_SPLITK_INKERNEL=0 / gs_debug_set_splitk_inkernel, too many tiles, or no memory): the
+// caller then keeps the separate reduce launch.
+unsigned* splitk_tickets(hipStream_t st, long ntiles);
 
 // norm.hip
 size_t bn_fused_reduce_bytes(long rows, int C);

@@ -25,7 +25,8 @@ extern "C" size_t gs_conv_bn_workspace_bytes(const gs_conv_desc* d) {
   // split-K slabs followed by the partials of the fused reduce + statistics pass; or the per-tile
   // partials of the conv epilogue (3 floats per channel and 64-row tile)
   const size_t fused = align256(a) + bn_fused_reduce_bytes(rows, d->Co);
-  const size_t tiles = (size_t)3 * d->Co * ((rows + 63) / 64) * sizeof(float);
+  // (behind the slabs when a split-K launch combines them itself and writes the tile partials)
+  const size_t tiles = align256(a) + (size_t)3 * d->Co * ((rows + 63) / 64) * sizeof(float);
   size_t m = a > b ? a : b;
   if (fused > m) m = fused;
   if (tiles > m) m = tiles;
@@ -49,7 +50,7 @@ extern "C" int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const f
   float* rm = bn->update_running ? bn->running_mean : nullptr;
   float* rv = bn->update_running ? bn->running_var : nullptr;
   if (info.mode == 1) {
-    rc = bn_tile_finalize(static_cast<const float*>(workspace), info.tiles_m, info.bm, rows, C,
+    rc = bn_tile_finalize(info.tile_part, info.tiles_m, info.bm, rows, C,
                           bn->gamma, bn->beta, bn->eps, bn->momentum, rm, rv, coeffs,
                           as_stream(stream));
   } else if (info.mode == 2) {

@@ -82,6 +82,11 @@ struct IgemmArgs {
   int bw_ldy, bw_ldact, bw_mode;
   const unsigned char* bw_mask;   // mode 3: [pixels][bw_ldmask] bytes, bit e of byte q <=> channel 4q+e
   int bw_ldmask;
+  // fast row kernels, split-K combined INSIDE the launch (see splitk_publish): one arrival counter
+  // per output tile, zero at rest (the last arriver puts it back to zero); NULL = the slabs are summed
+  // by a separate reduce launch
+  unsigned* tickets;
+  unsigned slab_bytes;            // extent of `slab` for the write-through buffer stores / loads
 };
 
 constexpr int kAffMaxC = 640;   // widest gathered operand of the supernet (stage-4 planes)
@@ -444,15 +449,150 @@ __global__ __launch_bounds__(NT) void igemm_rows_kernel(const IgemmArgs p) {
   }
 }
 
-// Shared epilogue of the row kernels: accumulators -> LDS -> coalesced float4 rows.
-template <int BM, int BN, bool QUAD = false>
-__device__ __forceinline__ void rows_epilogue(
+// ------------------------------------------------------------------------------------------
+// Split-K combined inside the launch (forward / dgrad row kernels).  The `nsplits` workgroups of an
+// output tile each publish their partial tile to the slab; the one that draws the last arrival
+// ticket sums the slabs in split order (the order of splitk_reduce_kernel: bit-identical) and runs
+// the ordinary epilogue on the sum — output store, bias / addend / accumulate, BatchNorm tile
+// statistics, BatchNorm-backward partials — so the separate reduce launch (6-14 us plus a kernel
+// boundary, 60-110 of them per training step) disappears.
+// Visibility does not depend on which XCD / CU the workgroups land on:
+//  * every slab store is a write-through (sc1) buffer store; EVERY storing wave drains its stores
+//    (s_waitcnt vmcnt(0)) before the workgroup barrier, and only then lane 0 adds to the counter
+//    (relaxed, agent scope: performed at the L2 all XCDs share through the fabric);
+//  * the last arriver reads the slabs ONLY with sc1 buffer loads (they bypass the CU's L1, which is
+//    never refreshed by other CUs' stores), its own partial included, so no acquire is needed;
+//  * nobody waits on anybody: a workgroup that is not last simply exits, so residency is irrelevant.
+// The counter is back at zero when the launch ends (the last arriver resets it: all `nsplits`
+// arrivals are in by then and nothing else touches it until the next launch on this stream).
+// ------------------------------------------------------------------------------------------
+constexpr int kAuxSc1 = 16;   // aux bit of the raw buffer intrinsics: sc1 (write-through / L1 bypass)
+
+template <int BM, int BN, bool QUAD>
+__device__ __forceinline__ bool splitk_publish(
     const IgemmArgs& p, float* lds, const f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN], int m0,
-    int n0, int t, int wave, int lane, int split) {
+    int n0, int t, int wave, int lane, int split, int tile) {
   using T = Tile<BM, BN>;
   float* Cs = lds;
   constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
-  if (p.bw_mode != 0 && !p.slab) {
+  constexpr int QPR = T::CCH / 4;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, p.slab_bytes, 0x00020000);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch > 0) __syncthreads();
+    acc_to_lds<BM, BN, QUAD>(Cs, acc, ch, wave, lane);
+    __syncthreads();
+    // (branch-free: an element outside the tile goes to an out-of-range offset, which a buffer store
+    // drops)
+    constexpr int NI = (BM * QPR + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int idx = t + i * NT;
+      const int row = idx / QPR, q = idx - row * QPR;
+      const int m = m0 + row;
+      const int col = n0 + ch * T::CCH + q * 4;
+      const bool ok = idx < BM * QPR && ch * T::CCH + q * 4 < BN && m < p.M && col < p.Nn;
+      const int rr = idx < BM * QPR ? row : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[rr * T::PC + q * 4]);
+      const unsigned off = ok ? (unsigned)((((long)split * p.M + m) * p.Nn + col) * 4) : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, kAuxSc1);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier
+  __syncthreads();
+  unsigned* flag = reinterpret_cast<unsigned*>(lds + T::C_SZ);
+  if (t == 0) {
+    const unsigned tk = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == (unsigned)(p.nsplits - 1))
+      __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = tk;
+  }
+  __syncthreads();
+  const bool last = *flag == (unsigned)(p.nsplits - 1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the slab loads below
+  return last;
+}
+
+// column chunk `ch` of the tile = fixed-order sum of the slabs, into the LDS C image (the layout
+// acc_to_lds leaves).  Latency, not bandwidth, is what this costs (one workgroup, 16 KB per slab, every
+// load a trip past the L1 to the far side of the fabric), so the loop is branch-free — an element
+// outside the tile or a slab index past nsplits reads from an out-of-range offset, which a buffer load
+// answers with zero without touching memory — and a thread has its NI quads x kZB slabs in flight at
+// once (a branch around a load would make hipcc drain vmcnt per element).
+template <int BM, int BN>
+__device__ __forceinline__ void slabs_to_lds(const IgemmArgs& p, float* __restrict__ Cs, int ch, int m0,
+                                             int n0, int t) {
+  using T = Tile<BM, BN>;
+  constexpr int QPR = T::CCH / 4;
+  constexpr int NI = (BM * QPR + NT - 1) / NT;
+  // slabs in flight per quad: 4 (16 loads, 64 registers) where the tile's registers leave room for it
+  // at three workgroups per CU (a split launch is planned at 2.5-3 per CU); the 80-wide tiles are at
+  // 156 registers already and 168 is the limit for three waves per SIMD
+  constexpr int kZB = BN > 64 ? 2 : 4;
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, p.slab_bytes, 0x00020000);
+  const unsigned zstride = (unsigned)((long)p.M * p.Nn * 4);
+  unsigned off[NI];
+  f32x4 v[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int idx = t + i * NT;
+    const int row = idx / QPR, q = idx - row * QPR;
+    const int m = m0 + row;
+    const int col = n0 + ch * T::CCH + q * 4;
+    const bool ok = idx < BM * QPR && ch * T::CCH + q * 4 < BN && m < p.M && col < p.Nn;
+    off[i] = ok ? (unsigned)(((long)m * p.Nn + col) * 4) : kOOB;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int z0 = 0; z0 < p.nsplits; z0 += kZB) {
+    u32x4 r[kZB][NI];
+#pragma unroll
+    for (int zz = 0; zz < kZB; ++zz)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const bool ok = z0 + zz < p.nsplits && off[i] != kOOB;
+        const unsigned o = ok ? off[i] + (unsigned)(z0 + zz) * zstride : kOOB;
+        r[zz][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, kAuxSc1);
+      }
+#pragma unroll
+    for (int zz = 0; zz < kZB; ++zz)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        // (the first slab is taken as it is, like splitk_reduce_kernel: 0 + x would lose a -0)
+        const f32x4 x = __builtin_bit_cast(f32x4, r[zz][i]);
+        const f32x4 sum = v[i] + x;
+        const bool first = z0 + zz == 0, live = z0 + zz < p.nsplits;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = first ? x[e] : (live ? sum[e] : v[i][e]);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int idx = t + i * NT;
+    const int row = idx / QPR, q = idx - row * QPR;
+    if (idx < BM * QPR) *reinterpret_cast<f32x4*>(&Cs[row * T::PC + q * 4]) = v[i];
+  }
+}
+
+// Shared epilogue of the row kernels: accumulators -> LDS -> coalesced float4 rows.
+// (`tile`: linear tile index of the launch, the workgroup's slot in IgemmArgs::tickets)
+template <int BM, int BN, bool QUAD = false, bool SK = false>
+__device__ __forceinline__ void rows_epilogue(
+    const IgemmArgs& p, float* lds, const f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN], int m0,
+    int n0, int t, int wave, int lane, int split, int tile) {
+  using T = Tile<BM, BN>;
+  float* Cs = lds;
+  constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
+  // split-K combined in the launch: everyone publishes, the tile's last arriver goes on with the sum
+  constexpr bool combine = SK;
+  if constexpr (SK) {
+    if (!splitk_publish<BM, BN, QUAD>(p, lds, acc, m0, n0, t, wave, lane, split, tile)) return;
+  }
+  const bool to_slab = p.slab && !combine;
+  if (p.bw_mode != 0 && !to_slab) {
     // ---- dgrad + BatchNorm-backward reduction of the producer layer (see IgemmArgs::bw_*) ----
     // fixed thread -> column-quad map (q = t & 15, rows t >> 4, +16, ...), so a thread keeps its
     // coefficients and its two partial sums in registers; the 16 threads of a quad are then summed
@@ -462,7 +602,8 @@ __device__ __forceinline__ void rows_epilogue(
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       if (ch > 0) __syncthreads();
-      acc_to_lds<BM, BN, QUAD>(Cs, acc, ch, wave, lane);
+      if constexpr (combine) slabs_to_lds<BM, BN>(p, Cs, ch, m0, n0, t);
+      else acc_to_lds<BM, BN, QUAD>(Cs, acc, ch, wave, lane);
       __syncthreads();
       const int col = n0 + ch * T::CCH + q * 4;
       const bool cv = q * 4 < T::CCH && ch * T::CCH + q * 4 < BN && col < p.Nn;
@@ -517,7 +658,8 @@ __device__ __forceinline__ void rows_epilogue(
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     if (ch > 0) __syncthreads();
-    acc_to_lds<BM, BN, QUAD>(Cs, acc, ch, wave, lane);
+    if constexpr (combine) slabs_to_lds<BM, BN>(p, Cs, ch, m0, n0, t);
+    else acc_to_lds<BM, BN, QUAD>(Cs, acc, ch, wave, lane);
     __syncthreads();
     constexpr int QPR = T::CCH / 4;
     for (int idx = t; idx < BM * QPR; idx += NT) {
@@ -526,7 +668,7 @@ __device__ __forceinline__ void rows_epilogue(
       const int col = n0 + ch * T::CCH + q * 4;
       if (ch * T::CCH + q * 4 < BN && m < p.M && col < p.Nn) {
         f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * T::PC + q * 4]);
-        if (p.slab) {
+        if (to_slab) {
           *reinterpret_cast<f32x4*>(p.slab + ((long)split * p.M + m) * p.Nn + col) = v;
         } else {
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
@@ -537,7 +679,7 @@ __device__ __forceinline__ void rows_epilogue(
         }
       }
     }
-    if (p.tile_stats && !p.slab) {
+    if (p.tile_stats && !to_slab) {
       // BatchNorm statistics of the tile while it is still in LDS (the BN that follows every conv
       // of this path would otherwise re-read the whole output from HBM): per column
       // s1 = sum(v - shift), s2 = sum (v - shift)^2 over the tile's rows, shift = its first row
@@ -815,7 +957,6 @@ __device__ __forceinline__ void pipelined_k_loop_pairs(
 // that contracts an overflowed element becomes NaN where the fp32 MFMA loop would give +-Inf; NaN
 // stays NaN.  Finite inputs (the only case the parity bar covers) are split exactly.
 // ------------------------------------------------------------------------------------------
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ u32x4 x3_pack(const u32x4 a, const u32x4 b) {
@@ -1043,8 +1184,11 @@ __device__ __forceinline__ unsigned long long gs_stamp() {
 // besides its AS data quads, the three coefficient quads of its K step (fetched from LDS when the
 // global loads are issued, two K steps before they are needed) and the tap-validity bits, so the
 // affine + ReLU + zero-padding select run in the store slot on values that are already there.
+// SK: this instantiation combines its split-K slabs itself (IgemmArgs::tickets set; splitk_publish).
+// A variant of its own because the combine's loads in flight cost registers the unsplit launches
+// would pay for in occupancy.
 template <int BM, int BN, bool BTRANS, int KS, int ABL = 0, int ROLE = 0, bool PIPE = true,
-          bool PAIR = false, bool AFF = false, bool X3 = false>
+          bool PAIR = false, bool AFF = false, bool X3 = false, bool SK = false>
 __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) {
   using T = Tile<BM, BN>;
   static_assert(!X3 || (PIPE && !PAIR && !AFF && ABL == 0 && BN <= 64), "bf16x3 loop: no loader fusion");
@@ -1367,7 +1511,8 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     float* keep = p.slab;
     IgemmArgs q = p;
     q.slab = nullptr;
-    rows_epilogue<BM, BN>(q, lds, acc, m0, n0, t, wave, lane, split);
+    q.tickets = nullptr;
+    rows_epilogue<BM, BN>(q, lds, acc, m0, n0, t, wave, lane, split, tile);
     const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
       unsigned long long* o = reinterpret_cast<unsigned long long*>(keep) + ((long)blockIdx.x * 4 + wave) * 8;
@@ -1379,7 +1524,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
       (void)d_bar;
     }
   } else {
-    rows_epilogue<BM, BN, (X3 && BN == 64)>(p, lds, acc, m0, n0, t, wave, lane, split);
+    rows_epilogue<BM, BN, (X3 && BN == 64), SK>(p, lds, acc, m0, n0, t, wave, lane, split, tile);
   }
 #undef GS_STAMP
 }
@@ -1803,6 +1948,13 @@ struct Plan {
   int bm, bn, splits, nk_total, nk_per_split, tiles_m, tiles_n;
 };
 
+// tiles whose fast row kernels have a split-K-combining instantiation: the planner's (64-row tiles,
+// columns <= 80); a forced wider plan keeps the separate reduce launch
+constexpr bool splitk_combine_tile(int bm, int bn) { return bm == 64 && bn <= 80; }
+static inline bool splitk_combine_ok(const Plan& pl) {
+  return pl.splits > 1 && splitk_combine_tile(pl.bm, pl.bn);
+}
+
 static const int kBN[6] = {128, 96, 80, 64, 48, 32};
 constexpr size_t kMaxSlabBytes = 96u << 20;
 
@@ -1837,6 +1989,7 @@ static int dyn_lds() { static const int v = env_int("GS_DYN_LDS", 0); return v; 
 static int pair_min_ksteps() { static const int v = env_int("GS_PAIR_MIN", 16); return v; }
 static int min_ksteps() { static const int v = env_int("GS_MIN_KSTEPS", 4); return v; }
 
+extern long long g_splitk_combined;   // capi_misc.hip: split-K launches that combined their slabs themselves
 extern int g_force_plan[3];  // capi_misc.hip: {bm, bn, splits} set by gs_debug_force_plan (0 = off)
 
 static Plan make_plan(int M, int Nn, int Ktot, bool allow_split, int max_splits = 64,
@@ -2045,16 +2198,27 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
   note_launch(BTRANS ? GS_OP_DGRAD : GS_OP_FORWARD, kloop, pl, a.a_coeffs != nullptr, a.bw_mode,
               2.0 * a.M * (double)a.Nn * a.Ktot);
   if (ROLE == 1 && !BTRANS) flops_add(&g_k3_flops[kloop], 2.0 * a.M * (double)a.Nn * a.Ktot);
+  if (a.tickets && splitk_combine_ok(pl)) __atomic_fetch_add(&g_splitk_combined, 1LL, __ATOMIC_RELAXED);
+  else a.tickets = nullptr;
+  // (GS_SKL: the split-K-combining instantiation when the launch carries arrival counters)
+#define GS_SKL(...)                                                                            \
+  do {                                                                                         \
+    if (a.tickets)                                                                             \
+      hipLaunchKernelGGL((igemm_rows_fast_kernel<__VA_ARGS__, true>), grid, block, lds_dyn, st, a);   \
+    else                                                                                       \
+      hipLaunchKernelGGL((igemm_rows_fast_kernel<__VA_ARGS__, false>), grid, block, lds_dyn, st, a);  \
+  } while (0)
+#define GS_PLAIN(...) \
+  hipLaunchKernelGGL((igemm_rows_fast_kernel<__VA_ARGS__, false>), grid, block, lds_dyn, st, a)
+  int lds_dyn = 0;
   if (kloop == GS_KLOOP_BF16X3) {
     if constexpr (BTRANS) {
-      if (pl.bn == 64)
-        hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, true, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
-      else
-        hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 48, true, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
+      if (pl.bn == 64) GS_SKL(64, 64, true, KS, 0, ROLE, true, false, false, true);
+      else GS_SKL(64, 48, true, KS, 0, ROLE, true, false, false, true);
     } else if (pl.bn == 64) {
-      hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 64, false, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
+      GS_SKL(64, 64, false, KS, 0, ROLE, true, false, false, true);
     } else {
-      hipLaunchKernelGGL((igemm_rows_fast_kernel<64, 48, false, KS, 0, ROLE, true, false, false, true>), grid, block, 0, st, a);
+      GS_SKL(64, 48, false, KS, 0, ROLE, true, false, false, true);
     }
     return;
   }
@@ -2062,10 +2226,13 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
     if (a.a_coeffs) {   // relu(bn(x)) evaluated in the loader: 64-row tiles (the planner's choice)
 #define GS_FAST_AFF(BN_)                                                                   \
   if (pl.bm == 64 && pl.bn == BN_) {                                                       \
-    if (pair)                                                                              \
-      hipLaunchKernelGGL((igemm_rows_fast_kernel<64, BN_, false, KS, 0, ROLE, true, true, true>), grid, block, 0, st, a); \
-    else                                                                                   \
-      hipLaunchKernelGGL((igemm_rows_fast_kernel<64, BN_, false, KS, 0, ROLE, true, false, true>), grid, block, 0, st, a); \
+    if constexpr (splitk_combine_tile(64, BN_)) {                                          \
+      if (pair) GS_SKL(64, BN_, false, KS, 0, ROLE, true, true, true, false);              \
+      else GS_SKL(64, BN_, false, KS, 0, ROLE, true, false, true, false);                  \
+    } else {                                                                               \
+      if (pair) GS_PLAIN(64, BN_, false, KS, 0, ROLE, true, true, true, false);            \
+      else GS_PLAIN(64, BN_, false, KS, 0, ROLE, true, false, true, false);                \
+    }                                                                                      \
     return;                                                                                \
   }
       GS_FAST_AFF(128) GS_FAST_AFF(96) GS_FAST_AFF(80) GS_FAST_AFF(64) GS_FAST_AFF(48) GS_FAST_AFF(32)
@@ -2073,17 +2240,23 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
       return;   // (unreachable: conv_in_affine_ok() admits only plans with 64-row tiles)
     }
   }
+  lds_dyn = dyn_lds();
 #define GS_FAST(BM_, BN_)                                                                  \
   if (pl.bm == BM_ && pl.bn == BN_) {                                                      \
-    if (pair)                                                                              \
-      hipLaunchKernelGGL((igemm_rows_fast_kernel<BM_, BN_, BTRANS, KS, 0, ROLE, true, true>), grid, block, dyn_lds(), st, a); \
-    else                                                                                   \
-      hipLaunchKernelGGL((igemm_rows_fast_kernel<BM_, BN_, BTRANS, KS, 0, ROLE>), grid, block, dyn_lds(), st, a); \
+    if constexpr (splitk_combine_tile(BM_, BN_)) {                                         \
+      if (pair) GS_SKL(BM_, BN_, BTRANS, KS, 0, ROLE, true, true, false, false);           \
+      else GS_SKL(BM_, BN_, BTRANS, KS, 0, ROLE, true, false, false, false);               \
+    } else {                                                                               \
+      if (pair) GS_PLAIN(BM_, BN_, BTRANS, KS, 0, ROLE, true, true, false, false);         \
+      else GS_PLAIN(BM_, BN_, BTRANS, KS, 0, ROLE, true, false, false, false);             \
+    }                                                                                      \
     return;                                                                                \
   }
   GS_FAST(128, 128) GS_FAST(128, 96) GS_FAST(128, 80) GS_FAST(128, 64) GS_FAST(128, 48) GS_FAST(128, 32)
   GS_FAST(64, 128) GS_FAST(64, 96) GS_FAST(64, 80) GS_FAST(64, 64) GS_FAST(64, 48) GS_FAST(64, 32)
 #undef GS_FAST
+#undef GS_SKL
+#undef GS_PLAIN
 }
 
 // the fast row kernel needs: NHWC vector source, channels per tap % BK == 0, 1x1 or 3x3

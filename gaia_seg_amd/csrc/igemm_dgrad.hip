@@ -87,11 +87,15 @@ static int dgrad_strided_fast(const gs_conv_desc* d, const float* dy, const floa
       a.src_bytes = (unsigned)((size_t)d->N * a.s_n * sizeof(float));
       a.dense_bytes = (unsigned)(((size_t)d->KH * d->KW - tap0) * d_tap * sizeof(float));
       a.o_s = s; a.o_ph = ph; a.o_pw = pw; a.o_Hq = Hq; a.o_Wq = Wq; a.o_H = d->H; a.o_W = d->W;
+      if (splitk_combine_ok(pl)) {   // slabs combined inside the launch (igemm_core.h splitk_publish)
+        a.tickets = splitk_tickets(st, (long)pl.tiles_m * pl.tiles_n);
+        a.slab_bytes = (unsigned)need;
+      }
       if (ks == 1) launch_rows_fast<true, 1>(pl, a, st);
       else launch_rows_fast<true, 3>(pl, a, st);
       int rc = launch_status();
       if (rc != GS_OK) return rc;
-      if (pl.splits > 1) {
+      if (pl.splits > 1 && !a.tickets) {
         launch_reduce(a, pl.splits, 0, st);
         rc = launch_status();
         if (rc != GS_OK) return rc;
@@ -116,7 +120,9 @@ size_t dgrad_bnbwd_part_bytes(const gs_conv_desc* d) {
   if (check_desc(d) != GS_OK || d->stride != 1 || (d->Ci & 3)) return 0;
   const Plan pl = plan_dgrad(d);
   const long M = (long)d->N * d->H * d->W;
-  if (pl.splits != 1) return align256(slab_bytes(pl, M, d->Ci)) + bn_reduce_bnbwd_bytes(M, d->Ci);
+  if (pl.splits != 1)   // slabs, then the partials of the slab reduce or (in-launch combine) of the tiles
+    return align256(slab_bytes(pl, M, d->Ci)) +
+           std::max(bn_reduce_bnbwd_bytes(M, d->Ci), (size_t)2 * d->Ci * pl.tiles_m * sizeof(float));
   return (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
 }
 
@@ -205,17 +211,25 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
     }
     return rc;
   }
+  // split-K on the fast row kernels: combined inside the launch (igemm_core.h splitk_publish); the
+  // tile's last workgroup then runs the unsplit epilogue, the fused BatchNorm-backward one included
+  if (splitk_combine_ok(pl) && d->stride == 1 && fast && need < (1ull << 32)) {
+    a.tickets = splitk_tickets(st, (long)pl.tiles_m * pl.tiles_n);
+    a.slab_bytes = (unsigned)need;
+  }
   if (!no_bnb && d->stride == 1 && fast && bnbwd_fuse_ok(bw, d, workspace)) {
-    if (pl.splits == 1) {
-      const size_t part_b = (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
-      if (part_b <= workspace_bytes) {
-        a.bw_y = bw->y; a.bw_ldy = bw->ldy; a.bw_act = bw->act; a.bw_ldact = bw->ldact;
-        a.bw_coeffs = bw->coeffs; a.bw_mode = bw->mode;
-        a.bw_mask = bw->mask; a.bw_ldmask = bw->ldmask;
-        a.bw_part = static_cast<float*>(workspace);
-        bnb = true;
-      }
+    const size_t part_b = (size_t)2 * d->Ci * pl.tiles_m * sizeof(float);
+    const size_t part_off = pl.splits > 1 ? align256(need) : 0;
+    if ((pl.splits == 1 || a.tickets) && part_off + part_b <= workspace_bytes) {
+      a.bw_y = bw->y; a.bw_ldy = bw->ldy; a.bw_act = bw->act; a.bw_ldact = bw->ldact;
+      a.bw_coeffs = bw->coeffs; a.bw_mode = bw->mode;
+      a.bw_mask = bw->mask; a.bw_ldmask = bw->ldmask;
+      a.bw_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_off);
+      bnb = true;
+    } else if (pl.splits == 1) {
+      // (no room for the tile partials: plain dgrad, the caller runs the BatchNorm reduction itself)
     } else if (align256(need) + bn_reduce_bnbwd_bytes(M, d->Ci) <= workspace_bytes) {
+      a.tickets = nullptr;
       bnb_split = true;   // the slab reduce does the masking and the sums
     }
   }
@@ -240,7 +254,7 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
     if (rc == GS_OK && fused) *fused = 1;
     return rc;
   }
-  if (pl.splits > 1) {
+  if (pl.splits > 1 && !a.tickets) {
     launch_reduce(a, pl.splits, 0, st);
     rc = launch_status();
   }

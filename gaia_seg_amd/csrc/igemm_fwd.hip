@@ -1,4 +1,6 @@
 // DynConv2d forward (implicit GEMM, fp32 MFMA) — see igemm_core.h
+#include <map>
+#include <mutex>
 #include "igemm_core.h"
 #include "igemm_stream.h"
 
@@ -25,6 +27,33 @@ extern "C" size_t gs_conv2d_workspace_bytes(const gs_conv_desc* d) {
 }
 
 namespace gs {
+extern int g_splitk_inkernel;   // capi_misc.hip: -1 = GS_SPLITK_INKERNEL (default on), 0 / 1 = forced
+constexpr long kMaxTickets = 16384;
+
+unsigned* splitk_tickets(hipStream_t st, long ntiles) {
+  static const int env_on = env_int("GS_SPLITK_INKERNEL", 1);
+  const int on = g_splitk_inkernel >= 0 ? g_splitk_inkernel : env_on;
+  if (!on || ntiles > kMaxTickets) return nullptr;
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, unsigned*> bufs;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(dev, st);
+  const auto it = bufs.find(key);
+  if (it != bufs.end()) return it->second;
+  unsigned* p = nullptr;
+  // zeroed ON the stream that will use it (torch's streams do not synchronise with the null stream)
+  if (hipMalloc(&p, kMaxTickets * sizeof(unsigned)) != hipSuccess ||
+      hipMemsetAsync(p, 0, kMaxTickets * sizeof(unsigned), st) != hipSuccess) {
+    (void)hipGetLastError();
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+  bufs[key] = p;
+  return p;
+}
+
 // the streaming 1x1 kernel takes a forward when: 1x1, stride 1, no padding, NHWC x with contiguous
 // pixel rows, no bias / addend, and stream_plan() finds a column-block width whose weights fit in LDS
 static StreamPlan stream_fwd_plan(const gs_conv_desc* d, bool fast, const float* bias,
@@ -98,7 +127,7 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
     }
     if (info) {
       info->mode = mode; info->splits = 1; info->tiles_m = tiles; info->bm = 128;
-      info->slab = nullptr; info->slab_bytes = 0; info->timed = false;
+      info->slab = nullptr; info->slab_bytes = 0; info->timed = false; info->tile_part = ts;
       info->flops = 2.0 * (double)M * d->Co * d->Ci * d->KH * d->KW;
     }
     return stem_forward(d, x, w, y, ts, nullptr, st);
@@ -117,7 +146,7 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
     if (info) {
       info->mode = mode; info->splits = 1; info->tiles_m = sp.row_groups;
       info->bm = sp.tiles_per_wg * kStreamBM;
-      info->slab = nullptr; info->slab_bytes = 0; info->timed = false;
+      info->slab = nullptr; info->slab_bytes = 0; info->timed = false; info->tile_part = a.tile_stats;
       info->flops = 2.0 * (double)M * d->Co * d->Ci;
     }
     a.slab = nullptr;
@@ -127,12 +156,20 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
   const bool timed = d->role == GS_CONV_ROLE_BOTTLENECK3X3 && k3_prof_on();
   if (timed) k3_prof_begin(st);
   const double flops = 2.0 * (double)M * d->Co * d->Ci * d->KH * d->KW;
+  // split-K on the fast row kernels: the slabs are combined inside the launch (splitk_publish), the
+  // epilogue of the tile's last workgroup is then the unsplit one (statistics included)
+  const bool stats_ok = want_stats && info && fast && !bias && !addend;
+  const size_t part_b = (size_t)3 * d->Co * pl.tiles_m * sizeof(float);
+  const size_t part_off = pl.splits > 1 ? ((need + 255) & ~(size_t)255) : 0;
+  const bool part_fits = workspace && part_off + part_b <= workspace_bytes && aligned16(workspace);
+  if (splitk_combine_ok(pl) && vec && fast && need < (1ull << 32) && (!stats_ok || part_fits))
+    a.tickets = splitk_tickets(st, (long)pl.tiles_m * pl.tiles_n);
+  a.slab_bytes = (unsigned)need;
   int mode = 0;
-  if (want_stats && info && fast && !bias && !addend) {
-    if (pl.splits == 1) {
-      const size_t part_b = (size_t)3 * d->Co * pl.tiles_m * sizeof(float);
-      if (workspace && part_b <= workspace_bytes && aligned16(workspace)) {
-        a.tile_stats = static_cast<float*>(workspace);
+  if (stats_ok) {
+    if (pl.splits == 1 || a.tickets) {
+      if (part_fits) {
+        a.tile_stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_off);
         mode = 1;
       }
     } else if (d->ldy >= d->Co && !timed) {
@@ -144,6 +181,7 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
   if (info) {
     info->mode = mode; info->splits = pl.splits; info->tiles_m = pl.tiles_m; info->bm = pl.bm;
     info->slab = a.slab; info->slab_bytes = need; info->timed = timed; info->flops = flops;
+    info->tile_part = a.tile_stats;
   }
   if (!vec) launch_rows<false, false, true, 0>(pl, a, st);
   else if (fast && ks == 1) launch_rows_fast<false, 1>(pl, a, st);
@@ -155,7 +193,7 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
   rc = launch_status();
   if (rc != GS_OK) return rc;
   if (mode == 2) return rc;   // the caller reduces the slabs (and closes the K3 timer)
-  if (pl.splits > 1) {
+  if (pl.splits > 1 && !a.tickets) {
     launch_reduce(a, pl.splits, 0, st, d->role == GS_CONV_ROLE_BOTTLENECK3X3 ? 1 : 0);
     rc = launch_status();
   }

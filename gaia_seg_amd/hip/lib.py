@@ -16,7 +16,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgaiaseg_hip.so")
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class HipLibraryError(RuntimeError):
@@ -156,6 +156,8 @@ PROTOTYPES = {
     "gs_debug_conv_launch_counts": (_i32, [POINTER(_i64), _i32]),
     "gs_debug_k3_flops": (_i32, [POINTER(_f64), _i32]),
     "gs_debug_set_x3_fwd": (_i32, [_i32]),
+    "gs_debug_set_splitk_inkernel": (_i32, [_i32]),
+    "gs_debug_splitk_combined": (_i64, [_i32]),
     "gs_debug_num_cu": (_i32, []),
     "gs_debug_set_stream_mode": (_i32, [_i32]),
     "gs_debug_conv_launch_flops": (_i32, [POINTER(_f64), _i32]),

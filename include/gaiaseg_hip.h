@@ -565,6 +565,15 @@ int gs_debug_conv_launch_flops(double* flops, int32_t reset);
  * csrc/igemm_core.h x3_fwd_mode for the parity margins behind that choice), -1 = back to the
  * GS_X3_FWD environment value.  Process-global. */
 int gs_debug_set_x3_fwd(int32_t mode);
+/* Split-K launches of the forward / data-gradient row kernels: 1 = every output tile's partial slabs
+ * are summed inside the launch by the tile's last-arriving workgroup, which then runs the unsplit
+ * epilogue (default; csrc/igemm_core.h splitk_publish), 0 = a separate reduce launch sums them,
+ * -1 = back to the GS_SPLITK_INKERNEL environment value.  Both sum in split order: the outputs are
+ * bit-identical.  Process-global. */
+int gs_debug_set_splitk_inkernel(int32_t mode);
+/* Split-K row launches since the last reset that combined their slabs inside the launch (the parity
+ * tests check that the shapes they compare really took that path); reset != 0 clears the count. */
+int64_t gs_debug_splitk_combined(int32_t reset);
 /* Compute units the planners assume: hipDeviceProp::multiProcessorCount of the current device, read
  * once at first use (256 on an MI355X; 256 is also assumed when no device is present). */
 int gs_debug_num_cu(void);
