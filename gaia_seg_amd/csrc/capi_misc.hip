@@ -40,6 +40,8 @@ int g_stream_mode = -1;
 int g_x3_fwd = -1;
 int g_splitk_inkernel = -1;
 long long g_splitk_combined = 0;
+int g_col_finalize = -1;
+long long g_col_finalized = 0;
 }
 extern "C" int gs_debug_last_conv_launch(gs_debug_launch* out) {
   if (!out) return GS_E_NULL;
@@ -82,6 +84,21 @@ extern "C" int gs_debug_set_splitk_inkernel(int32_t mode) {
 extern "C" int64_t gs_debug_splitk_combined(int32_t reset) {
   const long long v = __atomic_load_n(&gs::g_splitk_combined, __ATOMIC_RELAXED);
   if (reset) __atomic_store_n(&gs::g_splitk_combined, 0LL, __ATOMIC_RELAXED);
+  return v;
+}
+
+// Per-tile partials (BatchNorm statistics of a forward conv, BatchNorm-backward sums of a data
+// gradient) merged inside the launch by each column tile's last workgroup: 1 = on for launches with
+// few row tiles, 0 = always the separate bn_tile_finalize / sum_partials launch (default), -1 =
+// GS_COL_FINALIZE.
+extern "C" int gs_debug_set_col_finalize(int32_t mode) {
+  if (mode < -1 || mode > 1) return GS_E_BADARG;
+  gs::g_col_finalize = mode;
+  return GS_OK;
+}
+extern "C" int64_t gs_debug_col_finalized(int32_t reset) {
+  const long long v = __atomic_load_n(&gs::g_col_finalized, __ATOMIC_RELAXED);
+  if (reset) __atomic_store_n(&gs::g_col_finalized, 0LL, __ATOMIC_RELAXED);
   return v;
 }
 

@@ -8,6 +8,12 @@ struct ConvFwdInfo {
   int mode;          // 0: y complete; 1: per-tile BN partials written; 2: split-K slabs left to reduce
   int splits, tiles_m, bm;
   const float* tile_part;   // mode 1: where the per-tile partials are (inside the workspace)
+  // in: the BatchNorm behind this conv (gs_conv_bn_forward), so that a launch with few row tiles can
+  // merge its tile partials and write `fin_coeffs` itself (igemm_core.h column_finalize_stats);
+  // out: finalized = it did, no bn_tile_finalize launch is needed
+  const gs_bn_args* fin_bn;
+  float* fin_coeffs;
+  bool finalized;
   float* slab;       // mode 2: [splits][M][Co]
   size_t slab_bytes;
   bool timed;        // a K3 timer interval is open (mode 2: the caller closes it)
@@ -25,6 +31,11 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
 // off with GS_SPLITK_INKERNEL=0 / gs_debug_set_splitk_inkernel, too many tiles, or no memory): the
 // caller then keeps the separate reduce launch.
 unsigned* splitk_tickets(hipStream_t st, long ntiles);
+// Arrival counters per COLUMN tile of the launches that merge their per-tile partials themselves
+// (igemm_core.h column_arrive); NULL when switched off (the default; GS_COL_FINALIZE=1 /
+// gs_debug_set_col_finalize turn it on),
+// when the launch has more than GS_COL_FINALIZE_MAX (160) row tiles, or without memory.
+unsigned* column_tickets(hipStream_t st, long tiles_m, long tiles_n);
 
 // norm.hip
 size_t bn_fused_reduce_bytes(long rows, int C);

@@ -42,6 +42,7 @@ extern "C" int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const f
   if (!d || !bn || !coeffs) return GS_E_NULL;
   static const bool no_fuse = getenv("GS_NO_STATS_FUSION") != nullptr;
   ConvFwdInfo info{};
+  if (bn->use_batch_stats && !no_fuse) { info.fin_bn = bn; info.fin_coeffs = coeffs; }
   int rc = conv2d_forward_impl(d, x, w, nullptr, nullptr, y, workspace, workspace_bytes, stream,
                                bn->use_batch_stats && !no_fuse, &info);
   if (rc != GS_OK) return rc;
@@ -49,7 +50,9 @@ extern "C" int gs_conv_bn_forward(const gs_conv_desc* d, const float* x, const f
   const int32_t C = d->Co;
   float* rm = bn->update_running ? bn->running_mean : nullptr;
   float* rv = bn->update_running ? bn->running_var : nullptr;
-  if (info.mode == 1) {
+  if (info.mode == 1 && info.finalized) {
+    // the conv's last workgroups merged the tile partials and wrote the coefficients
+  } else if (info.mode == 1) {
     rc = bn_tile_finalize(info.tile_part, info.tiles_m, info.bm, rows, C,
                           bn->gamma, bn->beta, bn->eps, bn->momentum, rm, rv, coeffs,
                           as_stream(stream));

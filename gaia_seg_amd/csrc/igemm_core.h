@@ -87,6 +87,21 @@ struct IgemmArgs {
   // by a separate reduce launch
   unsigned* tickets;
   unsigned slab_bytes;            // extent of `slab` for the write-through buffer stores / loads
+  // fast row kernels with per-tile partials (tile_stats / bw_part) over at most a few hundred row
+  // tiles: the partials are merged INSIDE the launch by the last workgroup of every column tile
+  // (column_finalize_*), which writes the BatchNorm coefficients (forward) or the BatchNorm-backward
+  // sums (dgrad) itself — bn_tile_finalize / sum_partials launches disappear.  col_tickets: one
+  // arrival counter per column tile, zero at rest; NULL = the separate launch.
+  unsigned* col_tickets;
+  const float* fin_gamma;         // forward: the BatchNorm whose statistics the tiles carry
+  const float* fin_beta;
+  float* fin_running_mean;        // NULL: no running-statistics update
+  float* fin_running_var;
+  float* fin_coeffs;              // [scale | beta | mean | invstd][Nn]
+  float fin_eps, fin_momentum;
+  int fin_bm, fin_n_last;         // rows of a full tile / of the last tile
+  double fin_inv_M;               // 1 / rows
+  float* fin_bw_sums;             // dgrad: {sum g, sum g * xhat}[2][Nn]
 };
 
 constexpr int kAffMaxC = 640;   // widest gathered operand of the supernet (stage-4 planes)
@@ -577,9 +592,162 @@ __device__ __forceinline__ void slabs_to_lds(const IgemmArgs& p, float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Per-tile partials merged inside the launch (IgemmArgs::col_tickets).  Every workgroup that has
+// written its tile's partials (write-through stores, drained, then the workgroup barrier) adds to the
+// arrival counter of its COLUMN tile; the one that draws tiles_m - 1 reads the partials of all row
+// tiles of its columns back (sc1 loads: past the L1, wherever the writers ran) and finishes them.
+// Same hand-off as splitk_publish; nobody waits.  One workgroup reads tiles_m * BN * 12 (forward) or
+// * 8 (dgrad) bytes: the host enables this up to a few hundred row tiles (stages 2-4 of the
+// backbone, the heads), where the separate launch is nothing but latency (5-7 us + a kernel boundary).
+// MEASURED (r04, profiles/r04_splitk_inkernel.md): neutral on the training step — every workgroup,
+// not only the last, pays the drain + counter round trip (~3 us) before it can leave its CU slot, the
+// last one another ~3 us of dependent loads and double arithmetic, and the conv2 launches (the
+// headline kernel) run 4-6 % longer — so it is OFF by default (GS_COL_FINALIZE=1 turns it on).
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__device__ __forceinline__ bool column_arrive(const IgemmArgs& p, float* lds, int n0, int t) {
+  using T = Tile<BM, BN>;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its partial stores are out
+  __syncthreads();
+  unsigned* flag = reinterpret_cast<unsigned*>(lds + T::C_SZ);
+  if (t == 0) {
+    const int tn = n0 / BN;
+    const unsigned tk = __hip_atomic_fetch_add(p.col_tickets + tn, 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == (unsigned)(p.tiles_m - 1))
+      __hip_atomic_store(p.col_tickets + tn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = tk;
+  }
+  __syncthreads();
+  const bool last = *flag == (unsigned)(p.tiles_m - 1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return last;
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int mask) {
+  return __shfl_xor(v, mask, 64);
+}
+
+// forward: the arithmetic of bn_tile_finalize_kernel (norm.hip) for the channels [n0, n0 + BN) —
+// one pass over the tiles' {s1, s2, shift}, re-centred on tile 0's shift, in double; sixteen threads
+// share a channel quad (tiles p = sub, sub + 16, ...) and are combined with a fixed xor tree; sixteen
+// quads at a time.  Kept small in registers (two tiles = six loads in flight per thread): this code
+// sits behind every forward launch's epilogue, also the many-round ones whose occupancy matters.
+// (No private array is indexed with a run-time value here: see the NOTE in bn_tile_finalize_kernel.)
+template <int BN>
+__device__ __forceinline__ void column_finalize_stats(const IgemmArgs& p, int n0, int t) {
+  const int C = p.Nn, C4 = C >> 2, np = p.tiles_m;
+  const int nq = (min(BN, C - n0) + 3) >> 2;
+  const int sub = t & 15;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      p.tile_stats, 0, (unsigned)((long)3 * C * np * 4), 0x00020000);
+#pragma unroll 1
+  for (int qb = 0; qb < nq; qb += 16) {
+    const int qi = qb + (t >> 4);
+    const bool act = qi < nq;
+    const int q = (n0 >> 2) + (act ? qi : 0);
+    const unsigned o1 = (unsigned)(((0L * C4 + q) * np) * 16);
+    const unsigned o2 = (unsigned)(((1L * C4 + q) * np) * 16);
+    const unsigned o3 = (unsigned)(((2L * C4 + q) * np) * 16);
+    const f32x4 ref4 =
+        __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o3, 0, kAuxSc1));
+    const int fc = q * 4 + (sub & 3);
+    float g_pre = 1.f, be_pre = 0.f, rm_pre = 0.f, rv_pre = 0.f;
+    if (sub < 4) {
+      if (p.fin_gamma) g_pre = p.fin_gamma[fc];
+      if (p.fin_beta) be_pre = p.fin_beta[fc];
+      if (p.fin_running_mean) rm_pre = p.fin_running_mean[fc];
+      if (p.fin_running_var) rv_pre = p.fin_running_var[fc];
+    }
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    // (the 80-wide pair-loop tiles are at 156 registers: 168 is the limit for three waves per SIMD)
+    constexpr int kUnroll = BN > 64 ? 1 : 2;
+#pragma unroll kUnroll
+    for (int tp = sub; tp < np; tp += 16) {
+      const double n = (double)(tp == np - 1 ? p.fin_n_last : p.fin_bm);
+      const unsigned po = (unsigned)tp * 16u;
+      const f32x4 s1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o1 + po, 0, kAuxSc1));
+      const f32x4 s2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o2 + po, 0, kAuxSc1));
+      const f32x4 shv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o3 + po, 0, kAuxSc1));
+#define GS_ACC(E, A, B)                                              \
+      {                                                              \
+        const double d = (double)shv[E] - (double)ref4[E];           \
+        A += (double)s1[E] + n * d;                                  \
+        B += (double)s2[E] + d * (2.0 * (double)s1[E] + n * d);      \
+      }
+      GS_ACC(0, a0, b0) GS_ACC(1, a1, b1) GS_ACC(2, a2, b2) GS_ACC(3, a3, b3)
+#undef GS_ACC
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+      a0 += shfl_xor_d(a0, m); a1 += shfl_xor_d(a1, m); a2 += shfl_xor_d(a2, m); a3 += shfl_xor_d(a3, m);
+      b0 += shfl_xor_d(b0, m); b1 += shfl_xor_d(b1, m); b2 += shfl_xor_d(b2, m); b3 += shfl_xor_d(b3, m);
+    }
+    if (act && sub < 4) {
+      const double S1 = sub == 0 ? a0 : sub == 1 ? a1 : sub == 2 ? a2 : a3;
+      const double S2 = sub == 0 ? b0 : sub == 1 ? b1 : sub == 2 ? b2 : b3;
+      const float rf = sub == 0 ? ref4[0] : sub == 1 ? ref4[1] : sub == 2 ? ref4[2] : ref4[3];
+      const double MU = (double)rf + S1 * p.fin_inv_M;
+      double var = (S2 - S1 * S1 * p.fin_inv_M) * p.fin_inv_M;
+      if (var < 0.0) var = 0.0;
+      const double invstd = 1.0 / sqrt(var + (double)p.fin_eps);
+      float* co = p.fin_coeffs;
+      co[fc] = (float)((double)g_pre * invstd);
+      co[C + fc] = be_pre;
+      co[2 * C + fc] = (float)MU;
+      co[3 * C + fc] = (float)invstd;
+      if (p.fin_running_mean)
+        p.fin_running_mean[fc] = (1.f - p.fin_momentum) * rm_pre + p.fin_momentum * (float)MU;
+      if (p.fin_running_var) {
+        const double M = (double)p.M;
+        const double unbiased = p.M > 1 ? var * M / (M - 1.0) : var;
+        p.fin_running_var[fc] = (1.f - p.fin_momentum) * rv_pre + p.fin_momentum * (float)unbiased;
+      }
+    }
+  }
+}
+
+// dgrad: sums[k][c] = sum over the row tiles of bw_part[k][c / 4][tile] (k = 0: sum g, 1: sum g * xhat)
+// for the channels [n0, n0 + BN) — sum_partials_kernel's job; eight threads per (k, quad), double,
+// 32 (k, quad) items at a time.
+template <int BN>
+__device__ __forceinline__ void column_finalize_bwsums(const IgemmArgs& p, int n0, int t) {
+  const int C = p.Nn, C4 = C >> 2, np = p.tiles_m;
+  const int nq = (min(BN, C - n0) + 3) >> 2;
+  const int sub = t & 7;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      p.bw_part, 0, (unsigned)((long)2 * C * np * 4), 0x00020000);
+#pragma unroll 1
+  for (int ib = 0; ib < 2 * nq; ib += 32) {
+    const int item = ib + (t >> 3);              // item = k * nq + quad
+    const bool act = item < 2 * nq;
+    const int k = act ? item / nq : 0;
+    const int q = (n0 >> 2) + (act ? item - k * nq : 0);
+    const unsigned o = (unsigned)((((long)k * C4 + q) * np) * 16);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 4
+    for (int tp = sub; tp < np; tp += 8) {
+      const f32x4 v = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o + (unsigned)tp * 16u, 0, kAuxSc1));
+      a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      a0 += shfl_xor_d(a0, m); a1 += shfl_xor_d(a1, m); a2 += shfl_xor_d(a2, m); a3 += shfl_xor_d(a3, m);
+    }
+    if (act && sub == 0)
+      *reinterpret_cast<f32x4*>(p.fin_bw_sums + (long)k * C + q * 4) =
+          f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
+  }
+}
+
 // Shared epilogue of the row kernels: accumulators -> LDS -> coalesced float4 rows.
 // (`tile`: linear tile index of the launch, the workgroup's slot in IgemmArgs::tickets)
-template <int BM, int BN, bool QUAD = false, bool SK = false>
+// XE ("extended epilogue"): the instantiation for launches with few workgroups per CU that combine
+// their split-K slabs (p.tickets) and / or merge their tile partials (p.col_tickets) themselves; its
+// loads in flight and double arithmetic cost registers, so the many-round launches keep the plain one.
+template <int BM, int BN, bool QUAD = false, bool XE = false>
 __device__ __forceinline__ void rows_epilogue(
     const IgemmArgs& p, float* lds, const f32x4 (&acc)[Tile<BM, BN>::TM][Tile<BM, BN>::TN], int m0,
     int n0, int t, int wave, int lane, int split, int tile) {
@@ -587,9 +755,12 @@ __device__ __forceinline__ void rows_epilogue(
   float* Cs = lds;
   constexpr int NCH = (BN + T::CCH - 1) / T::CCH;
   // split-K combined in the launch: everyone publishes, the tile's last arriver goes on with the sum
-  constexpr bool combine = SK;
-  if constexpr (SK) {
-    if (!splitk_publish<BM, BN, QUAD>(p, lds, acc, m0, n0, t, wave, lane, split, tile)) return;
+  bool combine = false;
+  if constexpr (XE) {
+    if (p.tickets) {
+      if (!splitk_publish<BM, BN, QUAD>(p, lds, acc, m0, n0, t, wave, lane, split, tile)) return;
+      combine = true;
+    }
   }
   const bool to_slab = p.slab && !combine;
   if (p.bw_mode != 0 && !to_slab) {
@@ -602,7 +773,7 @@ __device__ __forceinline__ void rows_epilogue(
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       if (ch > 0) __syncthreads();
-      if constexpr (combine) slabs_to_lds<BM, BN>(p, Cs, ch, m0, n0, t);
+      if (XE && combine) slabs_to_lds<BM, BN>(p, Cs, ch, m0, n0, t);
       else acc_to_lds<BM, BN, QUAD>(Cs, acc, ch, wave, lane);
       __syncthreads();
       const int col = n0 + ch * T::CCH + q * 4;
@@ -648,17 +819,30 @@ __device__ __forceinline__ void rows_epilogue(
           s2 += red[256 + g * 16 + q];
         }
         const long C4 = p.Nn >> 2, np = p.tiles_m, tm = m0 / BM;
-        f32x4* part4 = reinterpret_cast<f32x4*>(p.bw_part);
-        part4[(0 * C4 + (col >> 2)) * np + tm] = s1;
-        part4[(1 * C4 + (col >> 2)) * np + tm] = s2;
+        if constexpr (XE) {
+          // (write-through: the column's last workgroup may read them back inside this launch)
+          const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+              p.bw_part, 0, (unsigned)((long)2 * p.Nn * np * 4), 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s1), rs_part,
+                                                 (unsigned)(((0 * C4 + (col >> 2)) * np + tm) * 16), 0, kAuxSc1);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s2), rs_part,
+                                                 (unsigned)(((1 * C4 + (col >> 2)) * np + tm) * 16), 0, kAuxSc1);
+        } else {
+          f32x4* part4 = reinterpret_cast<f32x4*>(p.bw_part);
+          part4[(0 * C4 + (col >> 2)) * np + tm] = s1;
+          part4[(1 * C4 + (col >> 2)) * np + tm] = s2;
+        }
       }
+    }
+    if constexpr (XE) {
+      if (p.col_tickets && column_arrive<BM, BN>(p, lds, n0, t)) column_finalize_bwsums<BN>(p, n0, t);
     }
     return;
   }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     if (ch > 0) __syncthreads();
-    if constexpr (combine) slabs_to_lds<BM, BN>(p, Cs, ch, m0, n0, t);
+    if (XE && combine) slabs_to_lds<BM, BN>(p, Cs, ch, m0, n0, t);
     else acc_to_lds<BM, BN, QUAD>(Cs, acc, ch, wave, lane);
     __syncthreads();
     constexpr int QPR = T::CCH / 4;
@@ -710,11 +894,23 @@ __device__ __forceinline__ void rows_epilogue(
         }
         const long C4 = p.Nn >> 2, np = p.tiles_m, tm = m0 / BM;
         const int cq = colg >> 2, e = colg & 3;
-        p.tile_stats[((0 * C4 + cq) * np + tm) * 4 + e] = s1;
-        p.tile_stats[((1 * C4 + cq) * np + tm) * 4 + e] = s2;
-        p.tile_stats[((2 * C4 + cq) * np + tm) * 4 + e] = shift;
+        float* ts1 = p.tile_stats + ((0 * C4 + cq) * np + tm) * 4 + e;
+        float* ts2 = p.tile_stats + ((1 * C4 + cq) * np + tm) * 4 + e;
+        float* ts3 = p.tile_stats + ((2 * C4 + cq) * np + tm) * 4 + e;
+        if constexpr (XE) {
+          // (write-through stores: the column's last workgroup may read them back inside this launch)
+          __hip_atomic_store(ts1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(ts2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(ts3, shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          *ts1 = s1; *ts2 = s2; *ts3 = shift;
+        }
       }
     }
+  }
+  if constexpr (XE) {
+    if (p.tile_stats && !to_slab && p.col_tickets && column_arrive<BM, BN>(p, lds, n0, t))
+      column_finalize_stats<BN>(p, n0, t);
   }
 }
 
@@ -1184,8 +1380,9 @@ __device__ __forceinline__ unsigned long long gs_stamp() {
 // besides its AS data quads, the three coefficient quads of its K step (fetched from LDS when the
 // global loads are issued, two K steps before they are needed) and the tap-validity bits, so the
 // affine + ReLU + zero-padding select run in the store slot on values that are already there.
-// SK: this instantiation combines its split-K slabs itself (IgemmArgs::tickets set; splitk_publish).
-// A variant of its own because the combine's loads in flight cost registers the unsplit launches
+// SK: the instantiation with the extended epilogue (rows_epilogue XE): launches that combine their
+// split-K slabs (IgemmArgs::tickets) and / or merge their tile partials (col_tickets) themselves.
+// A variant of its own because that code's loads in flight cost registers the many-round launches
 // would pay for in occupancy.
 template <int BM, int BN, bool BTRANS, int KS, int ABL = 0, int ROLE = 0, bool PIPE = true,
           bool PAIR = false, bool AFF = false, bool X3 = false, bool SK = false>
@@ -1512,6 +1709,7 @@ __global__ __launch_bounds__(NT) void igemm_rows_fast_kernel(const IgemmArgs p) 
     IgemmArgs q = p;
     q.slab = nullptr;
     q.tickets = nullptr;
+    q.col_tickets = nullptr;
     rows_epilogue<BM, BN>(q, lds, acc, m0, n0, t, wave, lane, split, tile);
     const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
@@ -1989,6 +2187,7 @@ static int dyn_lds() { static const int v = env_int("GS_DYN_LDS", 0); return v; 
 static int pair_min_ksteps() { static const int v = env_int("GS_PAIR_MIN", 16); return v; }
 static int min_ksteps() { static const int v = env_int("GS_MIN_KSTEPS", 4); return v; }
 
+extern long long g_col_finalized;    // capi_misc.hip: launches that merged their tile partials themselves
 extern long long g_splitk_combined;   // capi_misc.hip: split-K launches that combined their slabs themselves
 extern int g_force_plan[3];  // capi_misc.hip: {bm, bn, splits} set by gs_debug_force_plan (0 = off)
 
@@ -2200,10 +2399,11 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
   if (ROLE == 1 && !BTRANS) flops_add(&g_k3_flops[kloop], 2.0 * a.M * (double)a.Nn * a.Ktot);
   if (a.tickets && splitk_combine_ok(pl)) __atomic_fetch_add(&g_splitk_combined, 1LL, __ATOMIC_RELAXED);
   else a.tickets = nullptr;
-  // (GS_SKL: the split-K-combining instantiation when the launch carries arrival counters)
+  // (GS_SKL: the extended-epilogue instantiation when the launch carries arrival counters)
+  if (!splitk_combine_tile(pl.bm, pl.bn)) a.col_tickets = nullptr;   // (callers check; see column_tickets)
 #define GS_SKL(...)                                                                            \
   do {                                                                                         \
-    if (a.tickets)                                                                             \
+    if (a.tickets || a.col_tickets)                                                            \
       hipLaunchKernelGGL((igemm_rows_fast_kernel<__VA_ARGS__, true>), grid, block, lds_dyn, st, a);   \
     else                                                                                       \
       hipLaunchKernelGGL((igemm_rows_fast_kernel<__VA_ARGS__, false>), grid, block, lds_dyn, st, a);  \

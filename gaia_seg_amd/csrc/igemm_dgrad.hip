@@ -226,6 +226,12 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
       a.bw_mask = bw->mask; a.bw_ldmask = bw->ldmask;
       a.bw_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_off);
       bnb = true;
+      // few row tiles: the column's last workgroup sums the partials itself (column_finalize_bwsums)
+      if (splitk_combine_tile(pl.bm, pl.bn)) a.col_tickets = column_tickets(st, pl.tiles_m, pl.tiles_n);
+      if (a.col_tickets) {
+        a.fin_bw_sums = bw->sums;
+        __atomic_fetch_add(&g_col_finalized, 1LL, __ATOMIC_RELAXED);
+      }
     } else if (pl.splits == 1) {
       // (no room for the tile partials: plain dgrad, the caller runs the BatchNorm reduction itself)
     } else if (align256(need) + bn_reduce_bnbwd_bytes(M, d->Ci) <= workspace_bytes) {
@@ -259,7 +265,7 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
     rc = launch_status();
   }
   if (bnb && rc == GS_OK) {
-    rc = bn_sum_partials(a.bw_part, pl.tiles_m, 2 * d->Ci, bw->sums, st);
+    if (!a.col_tickets) rc = bn_sum_partials(a.bw_part, pl.tiles_m, 2 * d->Ci, bw->sums, st);
     if (fused) *fused = 1;
   }
   return rc;

@@ -30,10 +30,12 @@ namespace gs {
 extern int g_splitk_inkernel;   // capi_misc.hip: -1 = GS_SPLITK_INKERNEL (default on), 0 / 1 = forced
 constexpr long kMaxTickets = 16384;
 
-unsigned* splitk_tickets(hipStream_t st, long ntiles) {
-  static const int env_on = env_int("GS_SPLITK_INKERNEL", 1);
-  const int on = g_splitk_inkernel >= 0 ? g_splitk_inkernel : env_on;
-  if (!on || ntiles > kMaxTickets) return nullptr;
+extern int g_col_finalize;      // capi_misc.hip: -1 = GS_COL_FINALIZE (default OFF: measured neutral), 0 / 1 = forced
+constexpr long kMaxColTickets = 1024;
+
+// one zero-at-rest counter buffer per (device, stream): [kMaxTickets tile counters | kMaxColTickets
+// column counters]
+static unsigned* ticket_buffer(hipStream_t st) {
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, unsigned*> bufs;
   int dev = 0;
@@ -43,15 +45,31 @@ unsigned* splitk_tickets(hipStream_t st, long ntiles) {
   const auto it = bufs.find(key);
   if (it != bufs.end()) return it->second;
   unsigned* p = nullptr;
+  const size_t bytes = (kMaxTickets + kMaxColTickets) * sizeof(unsigned);
   // zeroed ON the stream that will use it (torch's streams do not synchronise with the null stream)
-  if (hipMalloc(&p, kMaxTickets * sizeof(unsigned)) != hipSuccess ||
-      hipMemsetAsync(p, 0, kMaxTickets * sizeof(unsigned), st) != hipSuccess) {
+  if (hipMalloc(&p, bytes) != hipSuccess || hipMemsetAsync(p, 0, bytes, st) != hipSuccess) {
     (void)hipGetLastError();
     if (p) (void)hipFree(p);
     p = nullptr;
   }
   bufs[key] = p;
   return p;
+}
+
+unsigned* splitk_tickets(hipStream_t st, long ntiles) {
+  static const int env_on = env_int("GS_SPLITK_INKERNEL", 1);
+  const int on = g_splitk_inkernel >= 0 ? g_splitk_inkernel : env_on;
+  if (!on || ntiles > kMaxTickets) return nullptr;
+  return ticket_buffer(st);
+}
+
+unsigned* column_tickets(hipStream_t st, long tiles_m, long tiles_n) {
+  static const int env_on = env_int("GS_COL_FINALIZE", 0);
+  static const int max_tiles = env_int("GS_COL_FINALIZE_MAX", 160);
+  const int on = g_col_finalize >= 0 ? g_col_finalize : env_on;
+  if (!on || tiles_m > max_tiles || tiles_n > kMaxColTickets) return nullptr;
+  unsigned* p = ticket_buffer(st);
+  return p ? p + kMaxTickets : nullptr;
 }
 
 // the streaming 1x1 kernel takes a forward when: 1x1, stride 1, no padding, NHWC x with contiguous
@@ -176,6 +194,24 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
       // (while the K3 timer runs, a split bottleneck conv2 keeps its own reduce launch, so that
       // the timed interval is exactly the conv and its slab reduction)
       mode = 2;
+    }
+  }
+  // few row tiles: the column's last workgroup merges the tile partials and writes the BatchNorm
+  // coefficients itself (column_finalize_stats) — no bn_tile_finalize launch
+  if (mode == 1 && info->fin_bn && info->fin_coeffs && (pl.splits == 1 || a.tickets) &&
+      splitk_combine_tile(pl.bm, pl.bn)) {
+    a.col_tickets = column_tickets(st, pl.tiles_m, pl.tiles_n);
+    if (a.col_tickets) {
+      const gs_bn_args* bn = info->fin_bn;
+      a.fin_gamma = bn->gamma; a.fin_beta = bn->beta;
+      a.fin_running_mean = bn->update_running ? bn->running_mean : nullptr;
+      a.fin_running_var = bn->update_running ? bn->running_var : nullptr;
+      a.fin_coeffs = info->fin_coeffs;
+      a.fin_eps = bn->eps; a.fin_momentum = bn->momentum;
+      a.fin_bm = pl.bm; a.fin_n_last = (int)(M - (long)(pl.tiles_m - 1) * pl.bm);
+      a.fin_inv_M = 1.0 / (double)M;
+      info->finalized = true;
+      __atomic_fetch_add(&g_col_finalized, 1LL, __ATOMIC_RELAXED);
     }
   }
   if (info) {

@@ -158,6 +158,8 @@ PROTOTYPES = {
     "gs_debug_set_x3_fwd": (_i32, [_i32]),
     "gs_debug_set_splitk_inkernel": (_i32, [_i32]),
     "gs_debug_splitk_combined": (_i64, [_i32]),
+    "gs_debug_set_col_finalize": (_i32, [_i32]),
+    "gs_debug_col_finalized": (_i64, [_i32]),
     "gs_debug_num_cu": (_i32, []),
     "gs_debug_set_stream_mode": (_i32, [_i32]),
     "gs_debug_conv_launch_flops": (_i32, [POINTER(_f64), _i32]),

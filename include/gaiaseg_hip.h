@@ -574,6 +574,16 @@ int gs_debug_set_splitk_inkernel(int32_t mode);
 /* Split-K row launches since the last reset that combined their slabs inside the launch (the parity
  * tests check that the shapes they compare really took that path); reset != 0 clears the count. */
 int64_t gs_debug_splitk_combined(int32_t reset);
+/* The per-tile partials a fused conv + BatchNorm call leaves (BatchNorm statistics of the forward,
+ * BatchNorm-backward sums of a data gradient with gs_bn_bwd_fuse): 1 = launches with at most
+ * GS_COL_FINALIZE_MAX (160) row tiles merge them inside the launch — the last workgroup of every
+ * column tile writes the coefficients / sums (csrc/igemm_core.h column_finalize_*), 0 = a separate
+ * launch merges them (the default: the in-launch form measured neutral on the training step, every
+ * workgroup pays the arrival hand-off), -1 = back to the GS_COL_FINALIZE environment value.
+ * Process-global.
+ * gs_debug_col_finalized: launches since the last reset that merged their partials themselves. */
+int gs_debug_set_col_finalize(int32_t mode);
+int64_t gs_debug_col_finalized(int32_t reset);
 /* Compute units the planners assume: hipDeviceProp::multiProcessorCount of the current device, read
  * once at first use (256 on an MI355X; 256 is also assumed when no device is present). */
 int gs_debug_num_cu(void);

@@ -18,7 +18,14 @@ PyTorch's conv2d on the CPU:
   * a back-to-back sequence of launches with changing inputs and shapes, alternating with
     separate-reduce launches that leave the slab's lines cached wherever their reduce ran: a stale
     slab line (L1 or a remote L2) anywhere would show as a bit difference.
-Every case asserts through gs_debug_splitk_combined that it really took the in-launch path."""
+Every case asserts through gs_debug_splitk_combined that it really took the in-launch path.
+
+The same hand-off one level up (column_arrive / column_finalize_*): a fused conv + BatchNorm launch with
+few row tiles merges its per-tile partials itself — the last workgroup of every column tile writes the
+BatchNorm coefficients (forward) or the BatchNorm-backward sums (data gradient) — instead of leaving
+them to a bn_tile_finalize / sum_partials launch.  gs_debug_set_col_finalize(0) puts those launches
+back; test_tile_partials_merged_in_the_launch compares the two (and float64 on the CPU) on split and
+unsplit shapes, ragged last tiles, 80-wide column tiles, and back to back with changing inputs."""
 import ctypes
 
 import pytest
@@ -30,6 +37,14 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 TOL = 3e-5
+
+
+@pytest.fixture()
+def col_mode(hip_lib):
+    def set_mode(mode):
+        assert hip_lib.gs_debug_set_col_finalize(mode) == 0
+    yield set_mode
+    hip_lib.gs_debug_set_col_finalize(-1)
 
 
 @pytest.fixture()
@@ -295,3 +310,124 @@ def test_fused_conv_bn_statistics_and_bn_backward_sums_from_the_last_arriver(hip
     assert rel_err(results[0][0], results[1][0]) < 2e-5
     for a, b in zip(results[0][1:], results[1][1:]):
         assert mean_err(a, b) < 2e-5
+
+
+COL_CASES = [
+    # ci   co   k  n  h   w   residual   (row tiles, split?)
+    (64, 64, 3, 2, 24, 32, False),        # 24 row tiles, split-K: slabs combined, then partials merged
+    (256, 256, 3, 2, 33, 33, False),      # 35 row tiles, ragged last tile (2178 rows)
+    (1024, 256, 1, 2, 32, 64, False),     # stage-3 conv1 at 512x1024: 64 row tiles, unsplit, 4 column tiles
+    (256, 1024, 1, 2, 32, 64, False),     # stage-3 conv3: 16 column tiles
+    # (no residual cases: with 4M outputs, relu(bn(y) + r) flips a mask bit against float64 about once per
+    # draw, on either path, and that moves the producer's gradients by 1e-4; the apply pass is not under
+    # test here — tests/test_hip_ops_gpu.py covers it)
+    (320, 320, 3, 2, 32, 64, False),      # MAX stage 3: 80-wide column tiles (two LDS chunks, 20 quads)
+    (128, 128, 3, 2, 64, 79, False),      # 158 row tiles: the largest the default limit (160) admits
+]
+
+
+@pytest.mark.parametrize("case", COL_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_tile_partials_merged_in_the_launch(hip_lib, col_mode, case):
+    from gaia_seg_amd.core.bricks import DynamicBatchNorm2d, DynamicConv2d, conv_bn_act
+    from gaia_seg_amd.hip.runtime import tape_function
+    ci, co, k, n, h, w, use_res = case
+    torch.manual_seed(17)
+    conv_a = DynamicConv2d(ci, ci, 1, bias=False)
+    bn_a = DynamicBatchNorm2d(ci)
+    conv = DynamicConv2d(ci, co, k, padding=k // 2, bias=False)
+    bn = DynamicBatchNorm2d(co)
+    for c in (conv_a, conv):
+        torch.nn.init.normal_(c.weight, 0, 1.0 / (c.weight[0].numel() ** 0.5))
+    for b in (bn_a, bn):
+        torch.nn.init.uniform_(b.weight, 0.5, 1.5)
+        torch.nn.init.normal_(b.bias, 0, 0.3)
+    x = torch.randn(n, ci, h, w) + 0.5
+    res = torch.randn(n, co, h, w) if use_res else None
+    params = [conv_a.weight, bn_a.weight, bn_a.bias, conv.weight, bn.weight, bn.bias]
+    refs = [p.detach().clone().double().requires_grad_(True) for p in params]
+    x_ref = x.clone().double().requires_grad_(True)
+    rm_a, rv_a = torch.zeros(ci, dtype=torch.float64), torch.ones(ci, dtype=torch.float64)
+    rm_b, rv_b = torch.zeros(co, dtype=torch.float64), torch.ones(co, dtype=torch.float64)
+    a_ref = F.relu(F.batch_norm(F.conv2d(x_ref, refs[0]), rm_a, rv_a, refs[1], refs[2], True, 0.1, 1e-5))
+    z_ref = F.batch_norm(F.conv2d(a_ref, refs[3], None, 1, k // 2), rm_b, rv_b, refs[4], refs[5], True,
+                         0.1, 1e-5)
+    if use_res:
+        z_ref = z_ref + res.double()
+    z_ref = F.relu(z_ref)
+    gz = torch.randn(z_ref.shape)
+    z_ref.backward(gz.double())
+
+    mods = [m.to(DEV) for m in (conv_a, bn_a, conv, bn)]
+    mods[1].train(), mods[3].train()
+
+    def mean_err(a, b):
+        return float((a.double() - b.double()).abs().mean() / b.double().abs().mean())
+    results = []
+    for mode in (1, 0, 1):           # (the third run: counters back at zero after the first)
+        col_mode(mode)
+        hip_lib.gs_debug_col_finalized(1)
+        for p in params:
+            p.grad = None
+        for b in (mods[1], mods[3]):
+            b.running_mean.zero_()
+            b.running_var.fill_(1.0)
+        xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        inputs = [xg]
+        if use_res:
+            inputs.append(res.to(DEV).contiguous(memory_format=torch.channels_last))
+
+        def run(tape, acts):
+            a = conv_bn_act(tape, mods[0], mods[1], acts[0], relu=True)
+            return [conv_bn_act(tape, mods[2], mods[3], a, relu=True,
+                                residual=acts[1] if use_res else None)]
+        z = tape_function(run, inputs, True)[0]
+        z.backward(gz.to(DEV))
+        torch.cuda.synchronize()
+        merged = hip_lib.gs_debug_col_finalized(1)
+        assert merged >= 2 if mode == 1 else merged == 0, merged   # `conv` forward + its data gradient
+        results.append([z.detach().cpu(), xg.grad.cpu()] + [p.grad.detach().cpu() for p in params] +
+                       [mods[3].running_mean.cpu().clone(), mods[3].running_var.cpu().clone()])
+    for got in results:
+        assert rel_err(got[0], z_ref) < 1e-4
+        assert mean_err(got[1], x_ref.grad) < 1e-5
+        for g, r in zip(got[2:8], refs):
+            assert mean_err(g, r.grad) < 1e-5
+        assert rel_err(got[8], rm_b) < 1e-5 and rel_err(got[9], rv_b) < 1e-5
+    # merged in the launch vs the separate launches: the same sums, rounded in another order
+    assert rel_err(results[0][0], results[1][0]) < 2e-5
+    for a, b in zip(results[0][1:], results[1][1:]):
+        assert mean_err(a, b) < 2e-5
+    # and reproducible: the second in-launch run is bit-identical to the first
+    for a, b in zip(results[0], results[2]):
+        assert torch.equal(a, b)
+
+
+def test_merged_partials_back_to_back_with_changing_inputs(hip_lib, col_mode):
+    """40 fused conv + BatchNorm forwards in a row on one stream (no host synchronisation), inputs
+    changing every time and two shapes alternating, so that the partials of every tile are rewritten by
+    each launch; every output must match the separate-finalize path for the same input (a stale
+    partial read by a column's last workgroup would move that column's normalisation)."""
+    from gaia_seg_amd.core.bricks import DynamicBatchNorm2d, DynamicConv2d, conv_bn_act
+    from gaia_seg_amd.hip.runtime import Act, Tape
+    torch.manual_seed(23)
+    layers = []
+    for ci, co, k, h, w in [(256, 256, 3, 32, 64), (1024, 256, 1, 32, 64)]:
+        conv = DynamicConv2d(ci, co, k, padding=k // 2, bias=False).to(DEV)
+        bn = DynamicBatchNorm2d(co).to(DEV).train()
+        layers.append((conv, bn, torch.randn(2, h, w, ci, device=DEV)))
+    outs, inputs = [], []
+    col_mode(1)
+    hip_lib.gs_debug_col_finalized(1)
+    for i in range(40):
+        conv, bn, x0 = layers[i % 2]
+        x = x0 * (1.0 + 0.0625 * i) + 0.125 * (i % 7)
+        outs.append(conv_bn_act(Tape(enabled=False), conv, bn, Act(x, True), relu=True).t)
+        inputs.append(x)
+    torch.cuda.synchronize()
+    assert hip_lib.gs_debug_col_finalized(1) == 40
+    col_mode(0)
+    for i in range(40):
+        conv, bn, _ = layers[i % 2]
+        want = conv_bn_act(Tape(enabled=False), conv, bn, Act(inputs[i], True), relu=True).t
+        assert rel_err(outs[i], want) < 2e-6, i
+    assert hip_lib.gs_debug_col_finalized(1) == 0
