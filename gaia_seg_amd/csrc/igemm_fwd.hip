@@ -1,6 +1,7 @@
 // DynConv2d forward (implicit GEMM, fp32 MFMA) — see igemm_core.h
 #include <map>
 #include <mutex>
+#include <vector>
 #include "igemm_core.h"
 #include "igemm_stream.h"
 
@@ -33,27 +34,43 @@ constexpr long kMaxTickets = 16384;
 extern int g_col_finalize;      // capi_misc.hip: -1 = GS_COL_FINALIZE (default OFF: measured neutral), 0 / 1 = forced
 constexpr long kMaxColTickets = 1024;
 
-// one zero-at-rest counter buffer per (device, stream): [kMaxTickets tile counters | kMaxColTickets
-// column counters]
+// One zero-at-rest counter buffer per (device, stream): [kMaxTickets tile counters | kMaxColTickets
+// column counters].  Buffers are carved out of chunks of kChunk that are allocated and zeroed OUTSIDE
+// stream capture (hipMalloc is not permitted while a stream captures, and a step graph is captured on
+// streams the eager warm-up never saw): a stream met for the first time during capture takes a spare
+// buffer of an earlier chunk; without one it gets NULL and that launch keeps the separate reduce.
 static unsigned* ticket_buffer(hipStream_t st) {
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, unsigned*> bufs;
+  static std::map<int, std::vector<unsigned*>> spares;   // per device
+  constexpr int kChunk = 16;
+  constexpr size_t kWords = kMaxTickets + kMaxColTickets;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lock(mu);
   const auto key = std::make_pair(dev, st);
   const auto it = bufs.find(key);
   if (it != bufs.end()) return it->second;
-  unsigned* p = nullptr;
-  const size_t bytes = (kMaxTickets + kMaxColTickets) * sizeof(unsigned);
-  // zeroed ON the stream that will use it (torch's streams do not synchronise with the null stream)
-  if (hipMalloc(&p, bytes) != hipSuccess || hipMemsetAsync(p, 0, bytes, st) != hipSuccess) {
-    (void)hipGetLastError();
-    if (p) (void)hipFree(p);
-    p = nullptr;
+  std::vector<unsigned*>& sp = spares[dev];
+  if (sp.empty()) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;   // (not cached: an eager call may allocate later)
+    unsigned* p = nullptr;
+    const size_t bytes = kChunk * kWords * sizeof(unsigned);
+    // zeroed on this stream and waited for: the spares go to other streams later
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemsetAsync(p, 0, bytes, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+      (void)hipGetLastError();
+      if (p) (void)hipFree(p);
+      return nullptr;
+    }
+    for (int i = kChunk - 1; i >= 0; --i) sp.push_back(p + (size_t)i * kWords);
   }
-  bufs[key] = p;
-  return p;
+  unsigned* buf = sp.back();
+  sp.pop_back();
+  bufs[key] = buf;
+  return buf;
 }
 
 unsigned* splitk_tickets(hipStream_t st, long ntiles) {
