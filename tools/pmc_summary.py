@@ -83,9 +83,9 @@ def hbm(fetch, write, out):
     assert n1 == n2 and n1 > 0, (n1, n2)
     per_launch = lambda v: v * 1024.0 / n1
     res = {
-        "kernel": "igemm_rows_fast_kernel<64,BN,false,3,0,1,...> + its split-K reduce (splitk_reduce_kernel<false,1> "
-                  "or the fused reduce+statistics splitk_reduce_stats_kernel<1>): bottleneck conv2 forward, "
-                  "sampled subnet mix of bench.py, bs 2, 512x1024",
+        "kernel": "igemm_rows_fast_kernel<64,BN,false,3,0,1,...> (split-K slabs combined inside the launch; with "
+                  "GS_SPLITK_INKERNEL=0 + its reduce launch splitk_reduce_kernel<false,1> / splitk_reduce_stats_kernel<1>): "
+                  "bottleneck conv2 forward, sampled subnet mix of bench.py, bs 2, 512x1024",
         "k3_launches": n1, "reduce_launches": nr1,
         "conv_fetch_bytes_per_launch": round(2 * per_launch(fc)),
         "conv_write_bytes_per_launch": round(per_launch(wc)),
