@@ -137,6 +137,43 @@ def test_forward_combined_in_the_launch_is_bit_identical_to_the_reduce_launch(hi
         assert bool((outs[0][..., co:] == 7.0).all())
 
 
+@pytest.mark.parametrize("bn", [48, 64, 80])
+@pytest.mark.parametrize("splits", [2, 3, 4, 5, 7, 8, 9, 14])
+def test_forced_split_counts_and_column_widths(hip_lib, splitk_mode, bn, splits):
+    """Every split count from 2 to 14 that sits on an edge of the combine's load batches (four slabs
+    in flight per output quad on 48 / 64-wide tiles, two on 80-wide ones: 2, 3 | 4, 5 | 7, 8, 9 | 14), on
+    each column width of the planner, with a ragged last row tile (33 x 33 pixels) and a ragged last
+    column tile: bit-identical to the reduce launch, bit-identical between two runs."""
+    from gaia_seg_amd.hip import lib
+    n, h, w, k = 2, 33, 33, 3
+    ci, co = 192, {48: 112, 64: 144, 80: 176}[bn]     # co: two full column tiles + a ragged third
+    case = (n, h, w, ci, co, k, 0, 0, 0, 0)
+    torch.manual_seed(splits * 100 + bn)
+    x = torch.randn(n, h, w, ci)
+    w_log = torch.randn(co, ci, k, k) * 0.1
+    y_ref = F.conv2d(x.permute(0, 3, 1, 2), w_log, None, 1, 1).permute(0, 2, 3, 1)
+    xg, wg = x.to(DEV), w_log.permute(2, 3, 1, 0).contiguous().to(DEV)
+    assert hip_lib.gs_debug_force_plan(64, bn, splits) == 0
+    try:
+        outs = []
+        for mode in (1, 1, 0):
+            splitk_mode(mode)
+            hip_lib.gs_debug_splitk_combined(1)
+            y = torch.full((n, h, w, co), 3.0, device=DEV)
+            d = _fwd_once(hip_lib, lib, case, xg, wg, None, None, y)
+            torch.cuda.synchronize()
+            rec = lib.DebugLaunch()
+            assert hip_lib.gs_debug_last_conv_launch(ctypes.byref(rec)) == 0
+            assert (rec.bm, rec.bn) == (64, bn) and rec.splits > 1
+            assert hip_lib.gs_debug_splitk_combined(1) == (1 if mode == 1 else 0)
+            outs.append(y.cpu())
+    finally:
+        hip_lib.gs_debug_force_plan(0, 0, 0)
+    assert torch.equal(outs[0], outs[1])          # two runs of the in-launch combine
+    _same(outs[0], outs[2], rec.splits)           # against the reduce launch
+    assert rel_err(outs[0], y_ref) < TOL
+
+
 # n  h   w   ci   co   k stride acc ldx_extra
 DGRAD_CASES = [
     (2, 24, 32, 64, 64, 3, 1, 0, 0),
