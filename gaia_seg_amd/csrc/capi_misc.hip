@@ -92,7 +92,7 @@ extern "C" int64_t gs_debug_splitk_combined(int32_t reset) {
 // few row tiles, 0 = always the separate bn_tile_finalize / sum_partials launch (default), -1 =
 // GS_COL_FINALIZE.
 extern "C" int gs_debug_set_col_finalize(int32_t mode) {
-  if (mode < -1 || mode > 1) return GS_E_BADARG;
+  if (mode < -1 || mode > 3) return GS_E_BADARG;   // mask: 1 = forward statistics, 2 = dgrad sums
   gs::g_col_finalize = mode;
   return GS_OK;
 }

@@ -35,7 +35,7 @@ unsigned* splitk_tickets(hipStream_t st, long ntiles);
 // (igemm_core.h column_arrive); NULL when switched off (the default; GS_COL_FINALIZE=1 /
 // gs_debug_set_col_finalize turn it on),
 // when the launch has more than GS_COL_FINALIZE_MAX (160) row tiles, or without memory.
-unsigned* column_tickets(hipStream_t st, long tiles_m, long tiles_n);
+unsigned* column_tickets(hipStream_t st, long tiles_m, long tiles_n, int kind /* 1 fwd, 2 dgrad */);
 
 // norm.hip
 size_t bn_fused_reduce_bytes(long rows, int C);

@@ -227,7 +227,7 @@ int conv2d_dgrad_impl(const gs_conv_desc* d, const float* dy, const float* w, fl
       a.bw_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_off);
       bnb = true;
       // few row tiles: the column's last workgroup sums the partials itself (column_finalize_bwsums)
-      if (splitk_combine_tile(pl.bm, pl.bn)) a.col_tickets = column_tickets(st, pl.tiles_m, pl.tiles_n);
+      if (splitk_combine_tile(pl.bm, pl.bn)) a.col_tickets = column_tickets(st, pl.tiles_m, pl.tiles_n, 2);
       if (a.col_tickets) {
         a.fin_bw_sums = bw->sums;
         __atomic_fetch_add(&g_col_finalized, 1LL, __ATOMIC_RELAXED);

@@ -80,11 +80,13 @@ unsigned* splitk_tickets(hipStream_t st, long ntiles) {
   return ticket_buffer(st);
 }
 
-unsigned* column_tickets(hipStream_t st, long tiles_m, long tiles_n) {
+// kind: 1 = forward (BatchNorm statistics), 2 = data gradient (BatchNorm-backward sums); the mode is a
+// mask of the kinds that merge inside the launch (GS_COL_FINALIZE = 0 ... 3)
+unsigned* column_tickets(hipStream_t st, long tiles_m, long tiles_n, int kind) {
   static const int env_on = env_int("GS_COL_FINALIZE", 0);
   static const int max_tiles = env_int("GS_COL_FINALIZE_MAX", 160);
   const int on = g_col_finalize >= 0 ? g_col_finalize : env_on;
-  if (!on || tiles_m > max_tiles || tiles_n > kMaxColTickets) return nullptr;
+  if (!(on & kind) || tiles_m > max_tiles || tiles_n > kMaxColTickets) return nullptr;
   unsigned* p = ticket_buffer(st);
   return p ? p + kMaxTickets : nullptr;
 }
@@ -217,7 +219,7 @@ int conv2d_forward_impl(const gs_conv_desc* d, const float* x, const float* w, c
   // coefficients itself (column_finalize_stats) — no bn_tile_finalize launch
   if (mode == 1 && info->fin_bn && info->fin_coeffs && (pl.splits == 1 || a.tickets) &&
       splitk_combine_tile(pl.bm, pl.bn)) {
-    a.col_tickets = column_tickets(st, pl.tiles_m, pl.tiles_n);
+    a.col_tickets = column_tickets(st, pl.tiles_m, pl.tiles_n, 1);
     if (a.col_tickets) {
       const gs_bn_args* bn = info->fin_bn;
       a.fin_gamma = bn->gamma; a.fin_beta = bn->beta;

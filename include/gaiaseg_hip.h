@@ -575,7 +575,8 @@ int gs_debug_set_splitk_inkernel(int32_t mode);
  * tests check that the shapes they compare really took that path); reset != 0 clears the count. */
 int64_t gs_debug_splitk_combined(int32_t reset);
 /* The per-tile partials a fused conv + BatchNorm call leaves (BatchNorm statistics of the forward,
- * BatchNorm-backward sums of a data gradient with gs_bn_bwd_fuse): 1 = launches with at most
+ * BatchNorm-backward sums of a data gradient with gs_bn_bwd_fuse).  mode is a mask — 1: the forward
+ * statistics, 2: the data gradient's sums, 3: both —; a set bit means launches with at most
  * GS_COL_FINALIZE_MAX (160) row tiles merge them inside the launch — the last workgroup of every
  * column tile writes the coefficients / sums (csrc/igemm_core.h column_finalize_*), 0 = a separate
  * launch merges them (the default: the in-launch form measured neutral on the training step, every

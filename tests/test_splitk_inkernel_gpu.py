@@ -400,7 +400,7 @@ def test_tile_partials_merged_in_the_launch(hip_lib, col_mode, case):
     def mean_err(a, b):
         return float((a.double() - b.double()).abs().mean() / b.double().abs().mean())
     results = []
-    for mode in (1, 0, 1):           # (the third run: counters back at zero after the first)
+    for mode in (3, 0, 3):           # (the third run: counters back at zero after the first)
         col_mode(mode)
         hip_lib.gs_debug_col_finalized(1)
         for p in params:
@@ -421,7 +421,7 @@ def test_tile_partials_merged_in_the_launch(hip_lib, col_mode, case):
         z.backward(gz.to(DEV))
         torch.cuda.synchronize()
         merged = hip_lib.gs_debug_col_finalized(1)
-        assert merged >= 2 if mode == 1 else merged == 0, merged   # `conv` forward + its data gradient
+        assert merged >= 2 if mode == 3 else merged == 0, merged   # `conv` forward + its data gradient
         results.append([z.detach().cpu(), xg.grad.cpu()] + [p.grad.detach().cpu() for p in params] +
                        [mods[3].running_mean.cpu().clone(), mods[3].running_var.cpu().clone()])
     for got in results:
