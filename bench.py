@@ -668,8 +668,15 @@ def main():
             k3_bound = 1.0 / ((1.0 - k3_x3) / FP32_MFMA_PEAK_TFLOPS + k3_x3 / X3_LDS_BOUND_TFLOPS)
             traffic, traffic_src = k3_traffic()
             out["roofline"] = {
-                "kernel": "igemm_rows_*_kernel<..., KS=3, ROLE=1> (+ its split-K reduce where used): "
+                "kernel": "igemm_rows_fast_kernel<..., KS=3, ROLE=1> (split-K slabs combined inside the launch): "
                           "the dynamic 3x3 bottleneck conv forward",
+                "timed_with": ("marker HIP events recorded on the launch stream in front of and behind each launch "
+                               "(GS_K3_TIMER_MARKERS: includes the gap between the markers and the dispatch)"
+                               if os.environ.get("GS_K3_TIMER_MARKERS") else
+                               "one pair of HIP events per launch, attached to the kernel's own dispatch on its stream "
+                               "(hipExtLaunchKernelGGL start / stop events: the dispatch's begin / end timestamps, the "
+                               "duration a rocprofv3 kernel trace reports; GS_K3_TIMER_MARKERS=1 gives the r01-r03 "
+                               "marker-event figure, 2-3 us more per launch)"),
                 "bound": "mfma", "achieved": round(achieved, 2),
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,

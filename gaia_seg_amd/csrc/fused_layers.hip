@@ -154,14 +154,46 @@ static hipEvent_t k3_event() {
   }
   return g_k3.pool[g_k3.used++];
 }
+// An interval = two events.  Where the role-1 op is ONE kernel (unsplit, or split-K combined inside the
+// launch) the events are attached to that kernel's dispatch (k3_launch_events -> hipExtLaunchKernelGGL)
+// and their difference is the kernel's own duration, the figure a rocprofv3 kernel trace reports; where
+// a reduce launch follows (GS_SPLITK_INKERNEL=0) or GS_K3_TIMER_MARKERS is set, they are marker events
+// recorded on the stream in front of the conv and behind the last launch (the r01-r03 method: it adds
+// the 2-3 us between the markers and the dispatch).
+struct K3Pending {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool open = false, start_set = false, stop_set = false;
+};
+static thread_local K3Pending t_k3;
 void k3_prof_begin(hipStream_t st) {
-  hipEvent_t e = k3_event();
-  if (e) (void)hipEventRecord(e, st);
+  (void)st;
+  t_k3 = K3Pending{};
+  t_k3.e0 = k3_event();
+  t_k3.e1 = k3_event();
+  t_k3.open = t_k3.e0 && t_k3.e1;
+}
+bool k3_launch_events(hipStream_t st, bool single_kernel, hipEvent_t* e0, hipEvent_t* e1) {
+  if (!t_k3.open || t_k3.start_set) return false;
+  static const bool markers = getenv("GS_K3_TIMER_MARKERS") != nullptr;
+  t_k3.start_set = true;
+  if (single_kernel && !markers) {
+    *e0 = t_k3.e0; *e1 = t_k3.e1;
+    t_k3.stop_set = true;
+    return true;
+  }
+  (void)hipEventRecord(t_k3.e0, st);
+  return false;
 }
 void k3_prof_end(hipStream_t st, double flops) {
-  hipEvent_t e = k3_event();
-  if (e) (void)hipEventRecord(e, st);
-  g_k3.flops += flops;
+  if (!t_k3.open) return;
+  if (!t_k3.start_set) {
+    // the op did not go through the fast row kernels: no interval (give the two events back)
+    if (g_k3.used >= 2) g_k3.used -= 2;
+  } else {
+    if (!t_k3.stop_set) (void)hipEventRecord(t_k3.e1, st);
+    g_k3.flops += flops;
+  }
+  t_k3 = K3Pending{};
 }
 }  // namespace gs
 

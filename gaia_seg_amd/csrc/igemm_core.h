@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <unordered_map>
+#include <hip/hip_ext.h>
 #include "common.h"
 
 namespace gs {
@@ -2382,6 +2383,21 @@ static inline int rows_fast_kloop(const Plan& pl, bool in_affine, int ks = 3) {
   return pair_loop_ok(pl) ? GS_KLOOP_FP32_PAIRS : GS_KLOOP_FP32;
 }
 
+// fused_layers.hip: the live timer of the role-1 (K3) launches.  If a timer interval is open for the
+// launch about to be issued on `st`: single_kernel (the launch is the whole op: unsplit, or split-K
+// combined inside the launch) -> true and the two events to attach to the kernel itself
+// (hipExtLaunchKernelGGL: they carry the dispatch's own begin / end timestamps, what rocprofv3's kernel
+// trace reports); otherwise a marker event is recorded in front of the launch and the caller's
+// k3_prof_end records the closing one behind the reduce launch.
+bool k3_launch_events(hipStream_t st, bool single_kernel, hipEvent_t* e0, hipEvent_t* e1);
+
+template <class K>
+static inline void launch_rows_kernel(K kernel, const dim3& grid, const dim3& block, int lds_dyn,
+                                      hipStream_t st, const IgemmArgs& a, hipEvent_t e0, hipEvent_t e1) {
+  if (e0) hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds_dyn, st, e0, e1, 0u, a);
+  else hipLaunchKernelGGL(kernel, grid, block, lds_dyn, st, a);
+}
+
 template <bool BTRANS, int KS, int ROLE = 0>
 static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t st) {
   IgemmArgs a = a_in;
@@ -2401,15 +2417,18 @@ static void launch_rows_fast(const Plan& pl, const IgemmArgs& a_in, hipStream_t 
   else a.tickets = nullptr;
   // (GS_SKL: the extended-epilogue instantiation when the launch carries arrival counters)
   if (!splitk_combine_tile(pl.bm, pl.bn)) a.col_tickets = nullptr;   // (callers check; see column_tickets)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (ROLE == 1 && !BTRANS && !k3_launch_events(st, pl.splits == 1 || a.tickets != nullptr, &ev0, &ev1))
+    ev0 = ev1 = nullptr;
 #define GS_SKL(...)                                                                            \
   do {                                                                                         \
     if (a.tickets || a.col_tickets)                                                            \
-      hipLaunchKernelGGL((igemm_rows_fast_kernel<__VA_ARGS__, true>), grid, block, lds_dyn, st, a);   \
+      launch_rows_kernel((igemm_rows_fast_kernel<__VA_ARGS__, true>), grid, block, lds_dyn, st, a, ev0, ev1);   \
     else                                                                                       \
-      hipLaunchKernelGGL((igemm_rows_fast_kernel<__VA_ARGS__, false>), grid, block, lds_dyn, st, a);  \
+      launch_rows_kernel((igemm_rows_fast_kernel<__VA_ARGS__, false>), grid, block, lds_dyn, st, a, ev0, ev1);  \
   } while (0)
 #define GS_PLAIN(...) \
-  hipLaunchKernelGGL((igemm_rows_fast_kernel<__VA_ARGS__, false>), grid, block, lds_dyn, st, a)
+  launch_rows_kernel((igemm_rows_fast_kernel<__VA_ARGS__, false>), grid, block, lds_dyn, st, a, ev0, ev1)
   int lds_dyn = 0;
   if (kloop == GS_KLOOP_BF16X3) {
     if constexpr (BTRANS) {
