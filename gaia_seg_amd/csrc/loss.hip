@@ -349,6 +349,39 @@ __device__ __forceinline__ float row16_sum_dpp(float v) {
   return v;
 }
 
+// Registers decide this kernel's speed: it is a chain of two global round trips (corner logits, then the
+// pixels' label / lse / weight) in front of ~2 us of arithmetic per wave, so what hides the latency is
+// the number of resident waves.  With all 20 classes' accumulators (80) and the hoisted corner vectors
+// (80) a wave held 195 registers = two waves per SIMD: 193 us at config 4.  The classes are therefore
+// walked in two halves of kRowCls = 10 (40 + 40 registers, four waves per SIMD), all corner vectors of
+// the tile staged in LDS once, and the first pixel's label / lse / weight loads are issued BEFORE the
+// barrier that publishes the corners, beside the corner loads instead of behind them.
+// (kRowCls: classes per register pass; GS_CE_ROWCLS = 10 / 5 / 4 selects 155 / 105 / 95 registers)
+// Four values per lane summed over the 16 lanes of a DPP row at once: two reduce-scatter steps inside
+// the quads (xor 1, xor 2: a lane keeps half of its values and adds its partner's copy of them), then the
+// four quads are added with two row_shr steps.  Lanes 12..15 of the row end up holding one total each:
+// lane 12 -> v0, 13 -> v2, 14 -> v1, 15 -> v3 (slot = ((l16 & 1) << 1) | ((l16 >> 1) & 1)).  11 VALU
+// operations and one store per class instead of 16 and four; fixed order.
+__device__ __forceinline__ float row16_sum4_dpp(float v0, float v1, float v2, float v3, int l16) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x),
+                                                                 decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  using std::integral_constant;
+  const bool b0 = (l16 & 1) != 0, b1 = (l16 & 2) != 0;
+  float k0 = b0 ? v2 : v0, g0 = b0 ? v0 : v2;
+  float k1 = b0 ? v3 : v1, g1 = b0 ? v1 : v3;
+  k0 += dpp(g0, integral_constant<int, 0xB1>{});   // quad_perm:[1,0,3,2]
+  k1 += dpp(g1, integral_constant<int, 0xB1>{});
+  float k = b1 ? k1 : k0;
+  const float g = b1 ? k0 : k1;
+  k += dpp(g, integral_constant<int, 0x4E>{});     // quad_perm:[2,3,0,1]
+  k += dpp(k, integral_constant<int, 0x114>{});    // row_shr:4
+  k += dpp(k, integral_constant<int, 0x118>{});    // row_shr:8
+  return k;
+}
+
+template <int kRowCls>
 __global__ __launch_bounds__(256) void ce_bwd_rowtile_kernel(
     const CeArgs a, const float* __restrict__ logits, const int64_t* __restrict__ labels,
     const float* __restrict__ pw, const float* __restrict__ cw, const float* __restrict__ lse,
@@ -378,6 +411,42 @@ __global__ __launch_bounds__(256) void ce_bwd_rowtile_kernel(
   const float* q10 = ub + (long)r1 * a.d.l_sh + (long)c0i * a.d.l_sw;
   const float* q11 = ub + (long)r1 * a.d.l_sh + (long)c1i * a.d.l_sw;
   float* prow = part + tile * 4 * cp;
+  // A pixel's state: interpolation weights, the four corner weights (x its loss coefficient), lse, label.
+  // Set up ONCE per pixel, outside the class passes (the lane's first pixel is the only one at ratios up
+  // to 4; its label / lse / weight loads are issued here, beside the corner logits).
+  struct Px {
+    bool ok;
+    float yl0, yl1, xl0, xl1, w00, w01, w10, w11, l;
+    int lab;
+  };
+  auto setup = [&](int q) -> Px {
+    Px p{};
+    p.ok = false;
+    if (q >= npx) return p;
+    const int Y = y0 + q / nx, X = x0 + q % nx;
+    const long pi = ((long)n * a.d.H + Y) * a.d.W + X;
+    const long lab = labels[pi];
+    if (lab == a.d.ignore_index || lab < 0 || lab >= a.d.Cls) return p;
+    float coef = gscale;
+    if (cw) coef *= cw[lab];
+    if (pw) coef *= pw[pi];
+    if (coef == 0.f) return p;
+    const Lerp ly = lerp_coord(Y, a.sh, a.d.h, al);
+    const Lerp lx = lerp_coord(X, a.sw, a.d.w, al);
+    // slot 1 = low-resolution index ty (tx), slot 0 = the one before it (both weights go there at
+    // the far border, where i1 == i0 == ty - 1)
+    const float wy1 = (ly.i0 == ty ? ly.l0 : 0.f) + (ly.i1 == ty ? ly.l1 : 0.f);
+    const float wy0 = (ly.i0 != ty ? ly.l0 : 0.f) + (ly.i1 != ty ? ly.l1 : 0.f);
+    const float wx1 = (lx.i0 == tx ? lx.l0 : 0.f) + (lx.i1 == tx ? lx.l1 : 0.f);
+    const float wx0 = (lx.i0 != tx ? lx.l0 : 0.f) + (lx.i1 != tx ? lx.l1 : 0.f);
+    p.yl0 = ly.l0; p.yl1 = ly.l1; p.xl0 = lx.l0; p.xl1 = lx.l1;
+    p.w00 = wy0 * wx0 * coef; p.w01 = wy0 * wx1 * coef; p.w10 = wy1 * wx0 * coef; p.w11 = wy1 * wx1 * coef;
+    p.l = lse[pi];
+    p.lab = (int)lab;
+    p.ok = true;
+    return p;
+  };
+  const Px p0 = setup(l16);
   for (int c0 = 0; c0 < a.d.Cls; c0 += TCH) {
     const int nc = min(TCH, a.d.Cls - c0);
     if (c0 > 0) __syncthreads();
@@ -387,47 +456,33 @@ __global__ __launch_bounds__(256) void ce_bwd_rowtile_kernel(
                                : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    float a00[TCH], a01[TCH], a10[TCH], a11[TCH];
+#pragma unroll 1
+    for (int hb = 0; hb < TCH; hb += kRowCls) {
+      float a00[kRowCls], a01[kRowCls], a10[kRowCls], a11[kRowCls];
 #pragma unroll
-    for (int c = 0; c < TCH; ++c) { a00[c] = 0.f; a01[c] = 0.f; a10[c] = 0.f; a11[c] = 0.f; }
-    for (int q = l16; q < npx; q += 16) {
-      const int Y = y0 + q / nx, X = x0 + q % nx;
-      const long pi = ((long)n * a.d.H + Y) * a.d.W + X;
-      const long lab = labels[pi];
-      if (lab == a.d.ignore_index || lab < 0 || lab >= a.d.Cls) continue;
-      float coef = gscale;
-      if (cw) coef *= cw[lab];
-      if (pw) coef *= pw[pi];
-      if (coef == 0.f) continue;
-      const Lerp ly = lerp_coord(Y, a.sh, a.d.h, al);
-      const Lerp lx = lerp_coord(X, a.sw, a.d.w, al);
-      // slot 1 = low-resolution index ty (tx), slot 0 = the one before it (both weights go there at
-      // the far border, where i1 == i0 == ty - 1)
-      const float wy1 = (ly.i0 == ty ? ly.l0 : 0.f) + (ly.i1 == ty ? ly.l1 : 0.f);
-      const float wy0 = (ly.i0 != ty ? ly.l0 : 0.f) + (ly.i1 != ty ? ly.l1 : 0.f);
-      const float wx1 = (lx.i0 == tx ? lx.l0 : 0.f) + (lx.i1 == tx ? lx.l1 : 0.f);
-      const float wx0 = (lx.i0 != tx ? lx.l0 : 0.f) + (lx.i1 != tx ? lx.l1 : 0.f);
-      const float w00 = wy0 * wx0 * coef, w01 = wy0 * wx1 * coef, w10 = wy1 * wx0 * coef,
-                  w11 = wy1 * wx1 * coef;
-      const float l = lse[pi];
-      const int labc = (int)lab - c0;
+      for (int c = 0; c < kRowCls; ++c) { a00[c] = 0.f; a01[c] = 0.f; a10[c] = 0.f; a11[c] = 0.f; }
+      auto accumulate = [&](const Px& p) {
+        const int labc = p.lab - c0 - hb;
 #pragma unroll
-      for (int c = 0; c < TCH; ++c) {
-        const float4 L = corner[grp][c];
-        // tap_value()'s association order, so that exp(z - lse) sums to one as in the forward
-        const float z = ly.l0 * (lx.l0 * L.x + lx.l1 * L.y) + ly.l1 * (lx.l0 * L.z + lx.l1 * L.w);
-        float p = expf(z - l);
-        if (c == labc) p -= 1.f;
-        a00[c] += w00 * p; a01[c] += w01 * p; a10[c] += w10 * p; a11[c] += w11 * p;
+        for (int c = 0; c < kRowCls; ++c) {
+          const float4 L = corner[grp][hb + c];
+          // tap_value()'s association order, so that exp(z - lse) sums to one as in the forward
+          const float z = p.yl0 * (p.xl0 * L.x + p.xl1 * L.y) + p.yl1 * (p.xl0 * L.z + p.xl1 * L.w);
+          float e = expf(z - p.l);
+          if (c == labc) e -= 1.f;
+          a00[c] += p.w00 * e; a01[c] += p.w01 * e; a10[c] += p.w10 * e; a11[c] += p.w11 * e;
+        }
+      };
+      if (p0.ok) accumulate(p0);
+      for (int q = l16 + 16; q < npx; q += 16) {
+        const Px p = setup(q);
+        if (p.ok) accumulate(p);
       }
-    }
+      const int slot = ((l16 & 1) << 1) | ((l16 >> 1) & 1);   // which corner sum lanes 12..15 end up with
 #pragma unroll
-    for (int c = 0; c < TCH; ++c) {
-      const float v0 = row16_sum_dpp(a00[c]), v1 = row16_sum_dpp(a01[c]), v2 = row16_sum_dpp(a10[c]),
-                  v3 = row16_sum_dpp(a11[c]);
-      if (live && l16 == 15 && c < nc) {
-        prow[0 * cp + c0 + c] = v0; prow[1 * cp + c0 + c] = v1;
-        prow[2 * cp + c0 + c] = v2; prow[3 * cp + c0 + c] = v3;
+      for (int c = 0; c < kRowCls; ++c) {
+        const float v = row16_sum4_dpp(a00[c], a01[c], a10[c], a11[c], l16);
+        if (live && l16 >= 12 && hb + c < nc) prow[slot * cp + c0 + hb + c] = v;
       }
     }
   }
@@ -611,8 +666,17 @@ extern "C" int gs_ce_backward_ws(const gs_ce_desc* d, const float* logits, const
   const int tiles = d->N * (d->h + 1) * (d->w + 1);
   if (rowtile) {
     const long ntiles = tiles;
-    hipLaunchKernelGGL(ce_bwd_rowtile_kernel, dim3((unsigned)((ntiles + 15) / 16)), dim3(256), 0, st, a,
-                       logits, labels, pixel_weight, class_weight, lse, grad_scale, ntiles, part, ld_d);
+    static const int rowcls = [] { const char* v = getenv("GS_CE_ROWCLS"); return v && *v ? atoi(v) : 5; }();
+    const dim3 rgrid((unsigned)((ntiles + 15) / 16));
+    if (rowcls == 10)
+      hipLaunchKernelGGL(ce_bwd_rowtile_kernel<10>, rgrid, dim3(256), 0, st, a, logits, labels,
+                         pixel_weight, class_weight, lse, grad_scale, ntiles, part, ld_d);
+    else if (rowcls == 4)
+      hipLaunchKernelGGL(ce_bwd_rowtile_kernel<4>, rgrid, dim3(256), 0, st, a, logits, labels,
+                         pixel_weight, class_weight, lse, grad_scale, ntiles, part, ld_d);
+    else
+      hipLaunchKernelGGL(ce_bwd_rowtile_kernel<5>, rgrid, dim3(256), 0, st, a, logits, labels,
+                         pixel_weight, class_weight, lse, grad_scale, ntiles, part, ld_d);
     const long total_r = (long)d->N * d->h * d->w * ld_d;
     hipLaunchKernelGGL(ce_bwd_gather_kernel, dim3(stream_grid(total_r, 256)), dim3(256), 0, st, part,
                        d->N, d->h, d->w, d->Cls, ld_d, dlogits, ld_d);
