@@ -481,7 +481,36 @@ class IterBasedRunner:
             self.set_arch(keep)
         return done
 
+    # The training step runs on a HIGH-PRIORITY stream (GS_TRAIN_PRIORITY=0: on the caller's stream):
+    # the weight-gradient stream, the optimizer stream and the gradient exchange keep normal priority,
+    # so when both have workgroups ready the dispatcher serves the chain every later kernel waits for
+    # — data gradients, BatchNorm passes — first and the weight gradients fill in behind.  Same
+    # kernels, same order on every stream, same results (tests/test_runner_gpu.py); r04 A/B on the
+    # sampled mix: 166.4 -> 169.9 images/s (five interleaved runs each, the two sets do not overlap),
+    # R50 unchanged (profiles/r04_stream_experiments.md).
+    # The stream becomes the CURRENT stream of the calling thread at the first train_iter and stays it
+    # (after waiting for what the caller had queued on its own stream): going back and forth between
+    # the legacy default stream and this one every step made every launch 3x as expensive on the host
+    # (45 us per conv + BN call instead of 15: measured, 166 -> 83 images/s).
+    TRAIN_PRIORITY = os.environ.get("GS_TRAIN_PRIORITY", "1") != "0"
+
+    def _enter_priority_stream(self):
+        dev = self.arena.device
+        if not self.TRAIN_PRIORITY or dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return
+        hp = self.__dict__.get("_hp_stream")
+        if hp is None:
+            hp = self._hp_stream = torch.cuda.Stream(device=dev, priority=-1)
+        cur = torch.cuda.current_stream(dev)
+        if cur != hp:
+            hp.wait_stream(cur)
+            torch.cuda.set_stream(hp)
+
     def train_iter(self, data_batch):
+        self._enter_priority_stream()
+        return self._train_iter(data_batch)
+
+    def _train_iter(self, data_batch):
         prof = self.host_prof
         t0 = time.perf_counter() if prof is not None else 0.0
         self.mark("step_begin")

@@ -30,6 +30,17 @@ def pytest_configure(config):
     torch.set_num_threads(usable_cores())
 
 
+@pytest.fixture(autouse=True)
+def _default_stream_after_each_test():
+    """A runner makes its high-priority training stream the current stream of the thread
+    (core/runner.py TRAIN_PRIORITY): every test starts on the default stream again."""
+    yield
+    import torch
+    if torch.cuda.is_available() and torch.cuda.current_stream() != torch.cuda.default_stream():
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
+
+
 @pytest.fixture(scope="session")
 def hip_lib():
     from gaia_seg_amd.hip import lib

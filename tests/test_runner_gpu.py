@@ -218,3 +218,41 @@ def test_optimizer_instalment_inside_backward_is_bitwise_the_same_training(hip_l
     assert torch.equal(p0, p1) and torch.equal(m0, m1)
     assert b0.keys() == b1.keys() and all(torch.equal(b0[k], b1[k]) for k in b0)
     assert float(m1.abs().max()) > 0
+
+
+def test_high_priority_training_stream_is_bitwise_the_same_training(hip_lib):
+    """IterBasedRunner.TRAIN_PRIORITY (the default): the step runs on a high-priority stream that the
+    first train_iter makes current; weight-gradient, optimizer and exchange streams keep normal priority.
+    Only the dispatcher's choice between ready workgroups changes, so after four steps over three
+    subnets every parameter, momentum buffer and BN statistic must equal, bit for bit, the same
+    training on the caller's (default) stream — a dependency that only the default stream happened to
+    provide would show here."""
+    from gaia_seg_amd.core.runner import IterBasedRunner
+    from gaia_seg_amd.models import build_segmentor
+    results = []
+    keep = IterBasedRunner.TRAIN_PRIORITY
+    default = torch.cuda.default_stream()
+    try:
+        for prio in (False, True):
+            IterBasedRunner.TRAIN_PRIORITY = prio
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(default)
+            torch.manual_seed(0)
+            model = build_segmentor(copy.deepcopy(model_cfg(fcn_head(), aux=True))).cuda().train()
+            runner, arena = _runner(model)
+            for it, name in enumerate(("max", "sub", "max", "min")):
+                runner.set_arch(_anchor(name))
+                runner.train_iter(_batch(it))
+            used = torch.cuda.current_stream()
+            torch.cuda.synchronize()
+            results.append((used != default, used.priority, arena.flat_param.clone(), arena.flat_mom.clone(),
+                            {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    finally:
+        IterBasedRunner.TRAIN_PRIORITY = keep
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(default)
+    (own0, pr0, p0, m0, b0), (own1, pr1, p1, m1, b1) = results
+    assert not own0 and own1 and pr1 < pr0        # (a smaller number is a higher priority)
+    assert torch.equal(p0, p1) and torch.equal(m0, m1)
+    assert b0.keys() == b1.keys() and all(torch.equal(b0[k], b1[k]) for k in b0)
+    assert float(m1.abs().max()) > 0
