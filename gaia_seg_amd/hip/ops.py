@@ -276,13 +276,15 @@ _branch_slot_of = {}     # raw stream handle -> slot (adopt_current_stream)
 _branch_origin = {}      # branch key -> raw handle of the stream it was last forked from
 _branch_dirty = {}
 _branch_cb_armed = False
+BRANCH_PRIORITY = os.environ.get("GS_BRANCH_PRIORITY", "0") == "1"
 
 
 def _branch_stream(dev, slot):
     key = (dev.type, dev.index, slot)
     s = _branch_streams.get(key)
     if s is None:
-        s = torch.cuda.Stream(device=dev)
+        # (GS_BRANCH_PRIORITY=1: the branch streams at the training stream's high priority — A/B knob)
+        s = torch.cuda.Stream(device=dev, priority=-1 if BRANCH_PRIORITY else 0)
         _branch_streams[key] = s
         _branch_slot_of[s.cuda_stream] = slot
     return s
