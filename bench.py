@@ -394,7 +394,19 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # the training step runs on a high-priority stream (core/runner.py TRAIN_PRIORITY): RCCL's own
+            # streams get the same priority, so that a bucket's all-reduce is dispatched when it is issued
+            # and not only when the compute queue runs dry
+            pg_opts = None
+            try:
+                pg_opts = dist.ProcessGroupNCCL.Options()
+                pg_opts.is_high_priority_stream = os.environ.get("GS_TRAIN_PRIORITY", "1") != "0"
+            except (AttributeError, TypeError):
+                pg_opts = None
+            if pg_opts is not None:
+                dist.init_process_group("nccl", device_id=dev, pg_options=pg_opts)
+            else:
+                dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
@@ -634,6 +646,8 @@ def main():
                 "collectives_per_step": round(collectives_per_step, 1),
                 "allreduce_bytes_per_step_per_rank": int(bytes_per_step),
                 "early_optimizer_steps": runner.early_steps,
+                "training_stream": ("high priority (-1); weight-gradient / optimizer streams 0; RCCL streams high"
+                                    if runner.TRAIN_PRIORITY else "the caller's stream"),
             },
         }
         hooks = [h for h in runner.hooks if isinstance(h, ManipulateArchHook)]

@@ -57,7 +57,17 @@ def init_dist(launcher, backend="nccl"):
     local_rank = int(os.environ["LOCAL_RANK"])
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank))
+    pg_opts = None
+    if backend == "nccl":   # RCCL's streams at the training stream's priority (core/runner.py TRAIN_PRIORITY)
+        try:
+            pg_opts = dist.ProcessGroupNCCL.Options()
+            pg_opts.is_high_priority_stream = os.environ.get("GS_TRAIN_PRIORITY", "1") != "0"
+        except (AttributeError, TypeError):
+            pg_opts = None
+    if pg_opts is not None:
+        dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank), pg_options=pg_opts)
+    else:
+        dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank))
 
 
 def get_root_logger(log_file=None, log_level=logging.INFO):
