@@ -40,12 +40,15 @@ _side_next = {}        # round-robin position per device
 _ws_side = _Workspace()
 
 
+SIDE_PRIORITY = int(os.environ.get("GS_SIDE_PRIORITY", "0"))   # A/B knob: priority of the weight-gradient stream(s)
+
+
 def _side_list(dev):
     key = (dev.type, dev.index)
     lst = _side_streams.get(key)
     if lst is None:
         # (stream priorities made no difference, r01 A/B)
-        lst = _side_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(N_SIDE)]
+        lst = _side_streams[key] = [torch.cuda.Stream(device=dev, priority=SIDE_PRIORITY) for _ in range(N_SIDE)]
     return lst
 
 
