@@ -265,8 +265,12 @@ int gs_conv_bn_backward(const gs_conv_desc* d, const float* x, const float* w, c
                         void* side_workspace, size_t side_workspace_bytes, void* stream,
                         void* side_stream, const gs_bn_bwd_fuse* input_bn, int32_t sums_ready);
 
-/* Live timer of the gs_conv2d_forward launches with role GS_CONV_ROLE_BOTTLENECK3X3 (HIP events on
- * the launch stream around the conv kernel and its split-K reduce): bench.py's `roofline`.
+/* Live timer of the forward launches with role GS_CONV_ROLE_BOTTLENECK3X3: bench.py's `roofline`.
+ * One pair of HIP events per op on the launch stream.  Where the op is ONE kernel (unsplit, or split-K
+ * combined inside the launch: the default) the pair is attached to that kernel's own dispatch
+ * (hipExtLaunchKernelGGL start / stop events: the dispatch's begin / end timestamps, what a rocprofv3
+ * kernel trace reports); where a reduce launch follows, or with GS_K3_TIMER_MARKERS set, the events are
+ * markers recorded in front of the conv and behind the last launch (2-3 us more per op).
  * enable(1) resets and starts, enable(0) stops; read after a device synchronize. */
 int gs_k3_timer_enable(int32_t on);
 int gs_k3_timer_read(int64_t* launches, double* total_ms, double* total_flops);
